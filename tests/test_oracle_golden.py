@@ -1,0 +1,99 @@
+"""The CPU oracle against the reference's own recorded runs (tests/golden/drone_n150_log.json =
+stdout of /root/reference/baseline_applications.ipynb cell 0; see tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bridge as ob
+
+
+@pytest.fixture(scope="module")
+def drone(golden_dir):
+    g = np.load(os.path.join(golden_dir, "drone_n150_problem.npz"))
+    log = json.load(open(os.path.join(golden_dir, "drone_n150_log.json")))
+    return g, log
+
+
+def _prob(g, R=None):
+    return ob.OracleProblem("drone", g["J"], float(g["dt"]), g["Q"], g["R"] if R is None else R, g["P"],
+                            g["q_ref"], g["xi_ref"])
+
+
+def test_ms_ilqr_reproduces_every_recorded_iteration(drone):
+    g, log = drone
+    r = ob.fit(_prob(g), g["q0"], g["xi0"], g["us_init"], mode="ms", max_iter=200, tol_grad=1e-12)
+    its = [it for it in log["ms"]["iterations"] if "J_new" in it]
+    assert r["n_iters"] == len(its) == 28 and r["converged"]
+    assert r["defect_hist"][0] == pytest.approx(its[0]["defect_lin"], rel=1e-12)
+    for k, it in enumerate(its):
+        assert r["J_hist"][k] == pytest.approx(it["J_new"], rel=1e-12), k
+        assert r["J_lin"][k] == pytest.approx(it["J_lin"], rel=1e-11), k
+        # the gradient decays to 1e-12 where it is rounding noise: absolute floor
+        assert r["grad_hist"][k] == pytest.approx(it["grad"], rel=1e-9, abs=5e-15), k
+        assert r["defect_hist"][k + 1] < 1e-12 and it["cb_defect"] < 1e-12
+        assert r["alpha_hist"][k] == it["cb_alpha"] == 1.0
+        assert r["mu_hist"][k] == it["cb_mu"] == 0.0
+    assert r["grad_hist"][28] == pytest.approx(log["ms"]["converged"]["grad"], rel=1e-2)
+    assert r["grad_hist"][28] < 1e-12
+
+
+def test_ss_ilqr_reproduces_line_search_and_failure(drone):
+    g, log = drone
+    r = ob.fit(_prob(g), g["q0"], g["xi0"], g["us_init"], mode="ss", max_iter=200, tol_grad=1e-12)
+    its = log["ss"]["iterations"]
+    assert r["n_iters"] == len(its) == 9
+    assert r["status"] == 2  # "Couldn't find descent direction" (traopt_controller.py:2005-2007)
+    for k, it in enumerate(its):
+        assert r["J_lin"][k] == pytest.approx(it["J_lin"], rel=1e-11)
+        assert r["grad_hist"][k] == pytest.approx(it["grad"], rel=1e-10)
+        trials = np.array([c for _, c in it["rollouts"]])
+        alphas = np.array([a for a, _ in it["rollouts"]])
+        assert r["n_trials"][k] == len(trials)
+        np.testing.assert_allclose(r["trial_J"][k][: len(trials)], trials, rtol=1e-11)
+        np.testing.assert_allclose(alphas, 1.1 ** (-np.arange(len(alphas)) ** 2.0), rtol=1e-15)
+        assert r["J_hist"][k] == pytest.approx(it["cb_J"], rel=1e-11)
+        assert r["alpha_hist"][k] == pytest.approx(it["cb_alpha"], rel=1e-15)
+    assert its[-1]["status"] == "failed" and r["n_trials"][8] == 13
+
+
+def test_R_inference_negative_control(drone):
+    """make_golden.py infers R = 1e-4 (the notebook source says 1e-5 but its output does not)."""
+    g, log = drone
+    target = log["ss"]["iterations"][0]["rollouts"][0][1]
+    for Rs in (1e-5, 8e-4, 95e-5, 1e-3, 110e-5):
+        r = ob.fit(_prob(g, np.eye(4) * Rs), g["q0"], g["xi0"], g["us_init"], mode="ss", max_iter=1, tol_grad=1e-12)
+        assert abs(r["trial_J"][0][0] / target - 1) > 0.15
+
+
+def test_quirks_are_pinned(drone):
+    """A 'corrected' gravity Jacobian (with m*g) or un-swapped coadjoint changes the recorded
+    gradient by far more than the match tolerance: checked through finite differences of f."""
+    g, _ = drone
+    prob = _prob(g)
+    rng = np.random.default_rng(1)
+    q = ob.se3_exp(rng.normal(size=6) * 0.5)
+    xi = rng.normal(size=6)
+    u = rng.normal(size=4)
+    Fx, Fu = ob.fx_fu(prob, q, xi)
+    f0 = ob.f(prob, q, xi, u)
+    eps = 1e-6
+    FD = np.zeros((12, 12))
+    for j in range(12):
+        d = np.zeros(12)
+        d[j] = eps
+        f1 = ob.f(prob, q @ ob.se3_exp(d[:6]), xi + d[6:], u)
+        FD[:6, j] = ob.rminus(f1[0], f0[0]) / eps
+        FD[6:, j] = (f1[1] - f0[1]) / eps
+    np.testing.assert_allclose(Fx[:6], FD[:6], atol=2e-8)       # pose rows are exact Jacobians
+    np.testing.assert_allclose(Fx[6:, :6] * 9.8, FD[6:, :6], atol=2e-7)  # Q2: m*g missing (m = 1)
+    assert np.abs(Fx[6:, 6:] - FD[6:, 6:]).max() > 1e-3          # Q1: swapped-twist coadjoint
+    FDu = np.zeros((12, 4))
+    for j in range(4):
+        du = np.zeros(4)
+        du[j] = eps
+        f1 = ob.f(prob, q, xi, u + du)
+        FDu[:6, j] = ob.rminus(f1[0], f0[0]) / eps
+        FDu[6:, j] = (f1[1] - f0[1]) / eps
+    np.testing.assert_allclose(Fu, FDu, atol=1e-9)
