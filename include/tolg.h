@@ -1,0 +1,137 @@
+/*
+ * tolg.h -- C ABI of libtolg_hip.so: batched tracking-iLQR on SE(3) for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of
+ * chenghuailin/trajectory_optimization_matrix_lie_groups.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).  The reference is pure
+ * Python (no FFI of its own); the binding a maintainer adds is the ctypes stub shown in
+ * INTEGRATION.md -- exactly what trajectory_optimization_matrix_lie_groups_amd/_capi.py does.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller (PyTorch-ROCm tensors);
+ *     the library never allocates, frees or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*).
+ *   - poses are 4x4 row-major homogeneous matrices, twists are [omega, v]
+ *     (traoptlibrary/traopt_utilis.py:43-92), fp64 throughout.
+ *   - return value: 0 ok, <0 argument / launch error (TOLG_E_*); per-trajectory outcomes are
+ *     written to d_status[B] (TOLG_ST_*).  No exception crosses this boundary.
+ */
+#ifndef TOLG_H
+#define TOLG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2 };
+enum { TOLG_MODE_MS = 0, TOLG_MODE_SS = 1 };
+enum { TOLG_E_ARG = -1, TOLG_E_WORKSPACE = -2, TOLG_E_LAUNCH = -3, TOLG_E_SINGULAR = -4 };
+enum { TOLG_ST_OK = 0, TOLG_ST_MAXREG = 1, TOLG_ST_NODESCENT = 2, TOLG_ST_NONFINITE = 3 };
+
+/* Problem = one (dynamics, cost) pair shared by the whole batch.
+ * Replaces the constructor arguments of SE3Dynamics / RigidBodyDynamics / DroneDynamics
+ * (traoptlibrary/traopt_dynamics.py:633-690, :906-970, :1214-1278) and of
+ * SE3TrackingQuadraticGaussNewtonCost (traoptlibrary/traopt_cost.py:587-622). */
+typedef struct {
+  int32_t kind;   /* TOLG_DYN_* */
+  int32_t m;      /* action size: 6 (SE3, RigidBody) or 4 (Drone) */
+  int32_t N;      /* horizon */
+  int32_t reserved;
+  double dt;
+  double J[36];   /* inertia diag(I_b, mass*I3); any SPD 6x6 is accepted */
+  double Q[144];  /* stage weights, 12x12 (only the two 6x6 diagonal blocks are read, as in
+                     traopt_cost.py:697,702) */
+  double P[144];  /* terminal weights */
+  double R[36];   /* m x m row-major */
+} tolg_problem;
+
+/* Replaces the keyword arguments of iLQR_Tracking_SE3_MS.__init__/fit and
+ * iLQR_Tracking_SE3.__init__/fit (traoptlibrary/traopt_controller.py:2359-2363, :2443-2445,
+ * :1837-1838, :1880-1881). */
+typedef struct {
+  int32_t mode;            /* TOLG_MODE_MS | TOLG_MODE_SS */
+  int32_t max_iter;        /* n_iterations */
+  int32_t line_search;     /* MS only */
+  int32_t rollout_linear;  /* rollout == 'linear' */
+  double tol_grad;         /* tol_grad_norm */
+  double tol_defect;       /* tol_d_norm (MS) */
+  double max_reg;          /* max_reg (1e10) */
+} tolg_options;
+
+typedef struct tolg_handle_s* tolg_handle_t;
+
+/* Bytes of device workspace tolg_create needs for batches up to max_batch and max_iter
+ * iterations. */
+size_t tolg_workspace_bytes(const tolg_problem* prob, int32_t max_batch);
+
+/* Build a solver instance on caller-provided device workspace.  d_q_ref [(N+1)][16],
+ * d_xi_ref [(N+1)][6] are read once (the q_ref "manifisation" of traopt_cost.py:614).
+ * The handle itself is a small host object; destroy frees only that. */
+int tolg_create(const tolg_problem* prob, const double* d_q_ref, const double* d_xi_ref,
+                int32_t max_batch, void* d_workspace, size_t workspace_bytes, void* stream,
+                tolg_handle_t* out);
+void tolg_destroy(tolg_handle_t h);
+
+/* fit for a batch of B independent trajectories -- replaces B calls of
+ * iLQR_Tracking_SE3_MS.fit (traoptlibrary/traopt_controller.py:2443-2639) or
+ * iLQR_Tracking_SE3.fit (:1880-2013), i.e. the joblib fan-out of
+ * visualization/perturb_all_compute.py:240-250.
+ *   in : d_x0_q [B][16], d_x0_xi [B][6], d_us_init [B][N][m]
+ *   out: d_xs_q [B][N+1][16], d_xs_xi [B][N+1][6], d_us [B][N][m]
+ *        d_J_hist [B][max_iter]        cost after iteration k (what on_iteration appends)
+ *        d_grad_hist [B][max_iter+1]   gradient norm evaluated in iteration k
+ *        d_defect_hist [B][max_iter+1] MS: [0] initial defect, [k+1] after iteration k
+ *        d_alpha_hist [B][max_iter], d_mu_hist [B][max_iter]
+ *        d_iters [B] callbacks made, d_status [B] TOLG_ST_*, d_converged [B]
+ * History buffers may be NULL.  Entries past d_iters[b] are left untouched. */
+int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
+                     const double* d_x0_xi, const double* d_us_init, double* d_xs_q, double* d_xs_xi,
+                     double* d_us, double* d_J_hist, double* d_grad_hist, double* d_defect_hist,
+                     double* d_alpha_hist, double* d_mu_hist, int32_t* d_iters, int32_t* d_status,
+                     int32_t* d_converged, void* stream);
+
+/* The same solve split in three, so a caller (bench.py, a receding-horizon loop) can issue the
+ * iterations in slices with the batch resident in HBM: begin = _initial_guess + first
+ * _linearization (traopt_controller.py:2486-2507); iterate = n_iter passes of the loop body
+ * (:2522-2626); end = unpack to the reference's 4x4 layout.  tolg_solve_batch == begin +
+ * iterate(max_iter) + end. */
+int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
+                     const double* d_x0_xi, const double* d_us_init, double* d_J_hist, double* d_grad_hist,
+                     double* d_defect_hist, double* d_alpha_hist, double* d_mu_hist, void* stream);
+int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream);
+int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                   int32_t* d_status, int32_t* d_converged, void* stream);
+
+/* One linearisation + backward pass on given trajectories (unit-parity entry point): replaces
+ * iLQR_Tracking_SE3_MS._linearization + _backward_pass + _gradient_wrt_control
+ * (traoptlibrary/traopt_controller.py:2823-3093; ms = 0: the SS variants :2098-2349).
+ *   in : d_xs_q [B][N+1][16], d_xs_xi [B][N+1][6], d_us [B][N][m], mu/delta in d_mu_delta [B][2]
+ *   out: d_Fx [B][N][12][12], d_d [B][N][12], d_lx [B][N+1][12], d_lxx11 [B][N+1][6][6],
+ *        d_k [B][N][m], d_K [B][N][m][12], d_J [B], d_dnorm [B], d_grad [B],
+ *        d_mu_delta updated.  Any output may be NULL. */
+int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_reg, int32_t B, const double* d_xs_q,
+                            const double* d_xs_xi, const double* d_us, double* d_mu_delta, double* d_Fx,
+                            double* d_d, double* d_lx, double* d_lxx11, double* d_k, double* d_K,
+                            double* d_J, double* d_dnorm, double* d_grad, void* stream);
+
+/* One closed-loop rollout with the gains left by the last tolg_linearize_backward on the same
+ * trajectories -- replaces iLQR_Tracking_SE3_MS._rollout (:2641-2740) / iLQR_Tracking_SE3._rollout
+ * (:2030-2082).  out: d_xs_q_new, d_xs_xi_new, d_us_new (same shapes as the inputs). */
+int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear, double alpha, int32_t B,
+                 double* d_xs_q_new, double* d_xs_xi_new, double* d_us_new, void* stream);
+
+/* Timing hook for bench.py: HIP-event time (ms) and launch count of the dominant kernel
+ * (backward sweep) accumulated since the last call with reset != 0.  Synchronises the recorded
+ * events only. */
+int tolg_kernel_time(tolg_handle_t h, int32_t reset, double* ms_backward, double* ms_rollout,
+                     double* ms_linearize, int64_t* launches);
+void tolg_enable_timing(tolg_handle_t h, int32_t on);
+
+const char* tolg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOLG_H */

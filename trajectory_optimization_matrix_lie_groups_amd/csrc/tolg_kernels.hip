@@ -1,0 +1,1334 @@
+// tolg_kernels.hip -- gfx950 kernels + C ABI (include/tolg.h) for batched tracking-iLQR on SE(3).
+//
+// Hot path of chenghuailin/trajectory_optimization_matrix_lie_groups rebuilt for MI355X:
+//   K1 k_linearize : one thread per (trajectory, knot): dynamics f, MS defect, F_x, cost
+//                    gradient/Gauss-Newton Hessian   (traopt_controller.py:2823-2910,
+//                    traopt_dynamics.py:763-850,1373-1482, traopt_cost.py:675-867)
+//   K2 k_backward  : Riccati sweep, 16 lanes per trajectory (4 trajectories per wavefront), one
+//                    12x12 column per lane held in VGPRs, lane-to-lane operand broadcast with
+//                    DPP row_newbcast fused into v_fmac_f64 -- no LDS traffic for the matrix
+//                    products (traopt_controller.py:2912-3093)
+//   K3 k_rollout   : closed-loop nonlinear/linear rollout (traopt_controller.py:2641-2740,
+//                    2030-2082)
+// Device layout: structure-of-arrays with the batch index fastest, poses as unit quaternion +
+// translation (see tolg_lie.h).  The 4x4 layout of the reference exists only at the C ABI.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/tolg.h"
+#include "tolg_lie.h"
+
+namespace tolg {
+
+// ------------------------------------------------------------------------------------------------
+// constants shared by the whole batch (device memory, read through the scalar cache)
+// ------------------------------------------------------------------------------------------------
+struct Consts {
+  int kind, m, N, pad;
+  double dt, mass, grav, pad2;
+  double J[36], Jinv[36], Ib[9];
+  double W1[36], W2[36], P1[36], P2[36];  // Q / P diagonal 6x6 blocks
+  double R[36];                           // m x m
+  double Bc[36];                          // 6 x m: J^-1 Pu dt (non-zero block of F_u)
+  double Pu[36];                          // 6 x m
+};
+
+struct Params {
+  const Consts* c;
+  int B, Bp, N, m;
+  double* cur;         // [13][N+1][Bp]  qx qy qz qw tx ty tz | xi(6)
+  double* cur_u;       // [m][N][Bp]
+  double* cand;
+  double* cand_u;
+  const double* ref;   // [N+1][13] reference pose (quat, pos) and twist, batch-shared
+  double* SA;          // [N][12][Bp][13]   F_x (cols 0..11) | defect d (col 12)
+  double* SL;          // [N+1][6][Bp][8]   l_xx11 (cols 0..5) | l_x[0:6] (col 6) | l_x[6:12] (col 7)
+  double* SC;          // [N+1][Bp] stage costs
+  double* SD;          // [N][Bp]   squared defects
+  double* GK;          // [N][m][Bp][13]    K (cols 0..11) | k (col 12)
+  double *mu, *delta, *Jc, *dn, *grad;
+  int *active, *iters, *status, *conv;
+  double *J_hist, *grad_hist, *defect_hist, *alpha_hist, *mu_hist;
+  int max_iter, pad;
+  double tol_grad, tol_defect, max_reg;
+};
+
+#define SIDX(c, i, b) ((((size_t)(c)) * (size_t)(P.N + 1) + (size_t)(i)) * (size_t)P.Bp + (size_t)(b))
+#define UIDX(c, i, b) ((((size_t)(c)) * (size_t)P.N + (size_t)(i)) * (size_t)P.Bp + (size_t)(b))
+#define SAIDX(i, r, b, j) (((((size_t)(i)) * 12 + (size_t)(r)) * (size_t)P.Bp + (size_t)(b)) * 13 + (size_t)(j))
+#define SLIDX(i, r, b, j) (((((size_t)(i)) * 6 + (size_t)(r)) * (size_t)P.Bp + (size_t)(b)) * 8 + (size_t)(j))
+#define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * (size_t)P.Bp + (size_t)(b)) * 13 + (size_t)(j))
+
+// ------------------------------------------------------------------------------------------------
+// shared per-thread dynamics pieces
+// ------------------------------------------------------------------------------------------------
+struct State { Pose X; V3 w, v; };
+
+TOLG_DEV State load_state(const Params& P, const double* __restrict__ s, int i, int b) {
+  State S;
+  S.X.q.x = s[SIDX(0, i, b)]; S.X.q.y = s[SIDX(1, i, b)]; S.X.q.z = s[SIDX(2, i, b)]; S.X.q.w = s[SIDX(3, i, b)];
+  S.X.t = v3(s[SIDX(4, i, b)], s[SIDX(5, i, b)], s[SIDX(6, i, b)]);
+  S.w = v3(s[SIDX(7, i, b)], s[SIDX(8, i, b)], s[SIDX(9, i, b)]);
+  S.v = v3(s[SIDX(10, i, b)], s[SIDX(11, i, b)], s[SIDX(12, i, b)]);
+  return S;
+}
+TOLG_DEV void store_state(const Params& P, double* __restrict__ s, int i, int b, const State& S) {
+  s[SIDX(0, i, b)] = S.X.q.x; s[SIDX(1, i, b)] = S.X.q.y; s[SIDX(2, i, b)] = S.X.q.z; s[SIDX(3, i, b)] = S.X.q.w;
+  s[SIDX(4, i, b)] = S.X.t.x; s[SIDX(5, i, b)] = S.X.t.y; s[SIDX(6, i, b)] = S.X.t.z;
+  s[SIDX(7, i, b)] = S.w.x; s[SIDX(8, i, b)] = S.w.y; s[SIDX(9, i, b)] = S.w.z;
+  s[SIDX(10, i, b)] = S.v.x; s[SIDX(11, i, b)] = S.v.y; s[SIDX(12, i, b)] = S.v.z;
+}
+
+// fd_euler (traopt_dynamics.py:763-787 SE3, :1373-1401 Drone, :1049-1077 RigidBody):
+// q+ = q Exp(xi dt) (re-normalised), xi+ = xi + J^-1 (ad(xi)^T J xi + g(q) + Pu u) dt
+template <int M>
+TOLG_DEV State dyn_f(const Consts& C, const State& S, const double (&u)[M]) {
+  State F;
+  double dt = C.dt;
+  Pose E = se3_exp(dt * S.w, dt * S.v);
+  F.X = se3_project(se3_compose(S.X, E));
+  double xi[6] = {S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
+  double Jxi[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += C.J[6 * a + k] * xi[k];
+    Jxi[a] = s;
+  }
+  V3 y1 = v3(Jxi[0], Jxi[1], Jxi[2]), y2 = v3(Jxi[3], Jxi[4], Jxi[5]);
+  V3 top = cross(y1, S.w) + cross(y2, S.v);  // ad(xi)^T y, upper half
+  V3 bot = cross(y2, S.w);
+  if (C.grav != 0.0) bot = bot + (C.mass * C.grav) * qrot_inv(S.X.q, v3(0, 0, -1.0));
+  double rhs[6] = {top.x, top.y, top.z, bot.x, bot.y, bot.z};
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int k = 0; k < M; k++) rhs[a] += C.Pu[a * M + k] * u[k];
+  double xn[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += C.Jinv[6 * a + k] * rhs[k];
+    xn[a] = xi[a] + dt * s;
+  }
+  F.w = v3(xn[0], xn[1], xn[2]);
+  F.v = v3(xn[3], xn[4], xn[5]);
+  return F;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack between the reference's 4x4 AoS layout (C ABI) and the device SoA layout
+// ------------------------------------------------------------------------------------------------
+TOLG_DEV Pose pose_from_m16(const double* __restrict__ Mx) {
+  double R[9] = {Mx[0], Mx[1], Mx[2], Mx[4], Mx[5], Mx[6], Mx[8], Mx[9], Mx[10]};
+  Pose X;
+  X.q = R_to_q(R);
+  X.t = v3(Mx[3], Mx[7], Mx[11]);
+  return X;
+}
+TOLG_DEV void pose_to_m16(Pose X, double* __restrict__ Mx) {
+  double R[9];
+  q_to_R(X.q, R);
+  Mx[0] = R[0]; Mx[1] = R[1]; Mx[2] = R[2];  Mx[3] = X.t.x;
+  Mx[4] = R[3]; Mx[5] = R[4]; Mx[6] = R[5];  Mx[7] = X.t.y;
+  Mx[8] = R[6]; Mx[9] = R[7]; Mx[10] = R[8]; Mx[11] = X.t.z;
+  Mx[12] = 0; Mx[13] = 0; Mx[14] = 0; Mx[15] = 1;
+}
+
+__global__ void k_pack_ref(int N, const double* __restrict__ q_ref, const double* __restrict__ xi_ref,
+                           double* __restrict__ ref) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > N) return;
+  Pose X = pose_from_m16(q_ref + 16 * (size_t)i);
+  double* r = ref + 13 * (size_t)i;
+  r[0] = X.q.x; r[1] = X.q.y; r[2] = X.q.z; r[3] = X.q.w; r[4] = X.t.x; r[5] = X.t.y; r[6] = X.t.z;
+  for (int a = 0; a < 6; a++) r[7 + a] = xi_ref[6 * (size_t)i + a];
+}
+
+// MS _initial_guess (traopt_controller.py:3123-3136): knot 0 = x0, knots 1..N = reference;
+// SS: only knot 0 (the rest comes from k_init_rollout).  Padded trajectories replicate b = B-1.
+__global__ void k_init(Params P, const double* __restrict__ x0_q, const double* __restrict__ x0_xi,
+                       const double* __restrict__ us_init, int ms) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  int bs = b < P.B ? b : P.B - 1;
+  State S;
+  if (i == 0) {
+    S.X = pose_from_m16(x0_q + 16 * (size_t)bs);
+    const double* x = x0_xi + 6 * (size_t)bs;
+    S.w = v3(x[0], x[1], x[2]);
+    S.v = v3(x[3], x[4], x[5]);
+  } else {
+    const double* r = P.ref + 13 * (size_t)i;
+    S.X.q.x = r[0]; S.X.q.y = r[1]; S.X.q.z = r[2]; S.X.q.w = r[3];
+    S.X.t = v3(r[4], r[5], r[6]);
+    S.w = v3(r[7], r[8], r[9]);
+    S.v = v3(r[10], r[11], r[12]);
+  }
+  if (i == 0 || ms) store_state(P, P.cur, i, b, S);
+  if (i < P.N)
+    for (int a = 0; a < P.m; a++) P.cur_u[UIDX(a, i, b)] = us_init[((size_t)bs * P.N + i) * P.m + a];
+  if (i == 0) {
+    P.mu[b] = 1.0; P.delta[b] = 2.0; P.active[b] = 1; P.iters[b] = 0; P.status[b] = 0; P.conv[b] = 0;
+    P.grad[b] = 0; P.Jc[b] = 0; P.dn[b] = 0;
+  }
+}
+
+// arbitrary trajectories in (unit-parity entry points)
+__global__ void k_pack_traj(Params P, const double* __restrict__ xs_q, const double* __restrict__ xs_xi,
+                            const double* __restrict__ us, const double* __restrict__ mu_delta) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  int bs = b < P.B ? b : P.B - 1;
+  State S;
+  S.X = pose_from_m16(xs_q + ((size_t)bs * (P.N + 1) + i) * 16);
+  const double* x = xs_xi + ((size_t)bs * (P.N + 1) + i) * 6;
+  S.w = v3(x[0], x[1], x[2]);
+  S.v = v3(x[3], x[4], x[5]);
+  store_state(P, P.cur, i, b, S);
+  if (i < P.N)
+    for (int a = 0; a < P.m; a++) P.cur_u[UIDX(a, i, b)] = us[((size_t)bs * P.N + i) * P.m + a];
+  if (i == 0) {
+    P.mu[b] = mu_delta ? mu_delta[2 * bs] : 1.0;
+    P.delta[b] = mu_delta ? mu_delta[2 * bs + 1] : 2.0;
+    P.active[b] = 1; P.iters[b] = 0; P.status[b] = 0; P.conv[b] = 0;
+  }
+}
+
+__global__ void k_unpack_traj(Params P, const double* __restrict__ s, const double* __restrict__ su,
+                              double* __restrict__ xs_q, double* __restrict__ xs_xi, double* __restrict__ us) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  if (b >= P.B) return;
+  State S = load_state(P, s, i, b);
+  if (xs_q) pose_to_m16(S.X, xs_q + ((size_t)b * (P.N + 1) + i) * 16);
+  if (xs_xi) {
+    double* x = xs_xi + ((size_t)b * (P.N + 1) + i) * 6;
+    x[0] = S.w.x; x[1] = S.w.y; x[2] = S.w.z; x[3] = S.v.x; x[4] = S.v.y; x[5] = S.v.z;
+  }
+  if (us && i < P.N)
+    for (int a = 0; a < P.m; a++) us[((size_t)b * P.N + i) * P.m + a] = su[UIDX(a, i, b)];
+}
+
+// SS _init_rollout (traopt_controller.py:2015-2028): x_{i+1} = f(x_i, u_i), one thread per trajectory
+template <int M>
+__global__ void k_init_rollout(Params P) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp) return;
+  const Consts& C = *P.c;
+  State S = load_state(P, P.cur, 0, b);
+  for (int i = 0; i < P.N; i++) {
+    double u[M];
+#pragma unroll
+    for (int a = 0; a < M; a++) u[a] = P.cur_u[UIDX(a, i, b)];
+    S = dyn_f<M>(C, S, u);
+    store_state(P, P.cur, i + 1, b, S);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: linearisation, one thread per (trajectory, knot)
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
+                                                    const double* __restrict__ src_u, double* __restrict__ dst,
+                                                    double* __restrict__ dst_u, int ms) {
+  const Consts& C = *P.c;
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  if (!P.active[b]) return;
+  const bool term = (i == P.N);
+  const double dt = C.dt;
+  State S = load_state(P, src, i, b);
+  if (dst) store_state(P, dst, i, b, S);
+  double u[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) u[a] = 0;
+  if (!term) {
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      u[a] = src_u[UIDX(a, i, b)];
+      if (dst_u) dst_u[UIDX(a, i, b)] = u[a];
+    }
+  }
+  // ---------------- cost: e = Log(X Xref^-1), J_e = Jr^-1(e) Ad(Xref)  (traopt_cost.py:659-839)
+  {
+    const double* r = P.ref + 13 * (size_t)i;
+    Pose Xr;
+    Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
+    Xr.t = v3(r[4], r[5], r[6]);
+    V3 ew, ev;
+    se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+    const double* W1 = term ? C.P1 : C.W1;
+    const double* W2 = term ? C.P2 : C.W2;
+    double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
+    double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
+    double th2 = dot(ew, ew);
+    double Ji[9], Qr[9], T1[9], Bm[9], Rr[9], Tr[9], Ja[9], Jb[9];
+    ljacinv33(neg(ew), ljacinv_coef(th2), Ji);  // Jr^-1(w) = Jl^-1(-w)
+    Q33(neg(ev), neg(ew), so3_coef(th2, true), Qr);
+    mul33(Ji, Qr, T1);
+    mul33(T1, Ji, Bm);  // rjacinv lower-left block = -Bm
+    q_to_R(Xr.q, Rr);
+    skew(Xr.t, Tr);
+    mul33(Ji, Rr, Ja);
+    mul33(Ji, Tr, T1);
+#pragma unroll
+    for (int k = 0; k < 9; k++) T1[k] -= Bm[k];
+    mul33(T1, Rr, Jb);
+    // J_e = [[Ja, 0],[Jb, Ja]]
+    double Je[36];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Je[6 * a + c] = Ja[3 * a + c];
+        Je[6 * a + c + 3] = 0;
+        Je[6 * (a + 3) + c] = Jb[3 * a + c];
+        Je[6 * (a + 3) + c + 3] = Ja[3 * a + c];
+      }
+    double We[6], W2v[6], l = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double s1 = 0, s2 = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { s1 += W1[6 * a + k] * e[k]; s2 += W2[6 * a + k] * ve[k]; }
+      We[a] = s1; W2v[a] = s2;
+      l += e[a] * s1 + ve[a] * s2;
+    }
+    if (!term) {
+#pragma unroll
+      for (int a = 0; a < M; a++)
+#pragma unroll
+        for (int k = 0; k < M; k++) l += u[a] * C.R[a * M + k] * u[k];
+    }
+    P.SC[(size_t)i * P.Bp + b] = l;
+    double WJ[36];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += W1[6 * a + k] * Je[6 * k + c];
+        WJ[6 * a + c] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += Je[6 * k + a] * WJ[6 * k + c];
+        P.SL[SLIDX(i, a, b, c)] = 2 * s;
+      }
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += Je[6 * k + a] * We[k];
+      P.SL[SLIDX(i, a, b, 6)] = 2 * s;
+      P.SL[SLIDX(i, a, b, 7)] = 2 * W2v[a];
+    }
+  }
+  if (term) return;
+  // ---------------- dynamics Jacobian (traopt_dynamics.py:802-837, :1416-1469)
+  V3 wd = dt * S.w, vd = dt * S.v;
+  SO3Coef kc = so3_coef(dot(wd, wd), true);
+  Pose E;
+  E.q = so3_exp(wd);
+  E.t = ljac_apply(wd, kc, vd);
+  {
+    // A11 = Ad(Exp(tau))^-1 = Ad(E^-1) = [[Ri,0],[[ti]x Ri, Ri]]
+    Pose Ei = se3_inverse(E);
+    double Ri[9], Ti[9], TR[9];
+    q_to_R(Ei.q, Ri);
+    skew(Ei.t, Ti);
+    mul33(Ti, Ri, TR);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        P.SA[SAIDX(i, a, b, c)] = Ri[3 * a + c];
+        P.SA[SAIDX(i, a, b, c + 3)] = 0;
+        P.SA[SAIDX(i, a + 3, b, c)] = TR[3 * a + c];
+        P.SA[SAIDX(i, a + 3, b, c + 3)] = Ri[3 * a + c];
+      }
+    // A12 = Jr(tau) dt = [[Jr3,0],[Qr,Jr3]] dt, Jr(tau) = Jl(-tau)
+    double Jr3[9], Qr[9];
+    ljac33(neg(wd), kc, Jr3);
+    Q33(neg(vd), neg(wd), kc, Qr);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        P.SA[SAIDX(i, a, b, c + 6)] = dt * Jr3[3 * a + c];
+        P.SA[SAIDX(i, a, b, c + 9)] = 0;
+        P.SA[SAIDX(i, a + 3, b, c + 6)] = dt * Qr[3 * a + c];
+        P.SA[SAIDX(i, a + 3, b, c + 9)] = dt * Jr3[3 * a + c];
+      }
+  }
+  {
+    // A22 = I + H dt, H = J^-1 (coadjoint([v, w]) J + G)   <- literal swapped twist (App. C-Q1)
+    double Mx[36];
+    double Sv[9], Sw[9], SIw[9];
+    skew(S.v, Sv);
+    skew(S.w, Sw);
+    V3 Ibw = v3(C.Ib[0] * S.w.x + C.Ib[1] * S.w.y + C.Ib[2] * S.w.z, C.Ib[3] * S.w.x + C.Ib[4] * S.w.y + C.Ib[5] * S.w.z,
+                C.Ib[6] * S.w.x + C.Ib[7] * S.w.y + C.Ib[8] * S.w.z);
+    skew(Ibw, SIw);
+    // coadjoint([v,w]) = [[-Sv, -Sw],[0, -Sv]]
+    double co[36];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        co[6 * a + c] = -Sv[3 * a + c];
+        co[6 * a + c + 3] = -Sw[3 * a + c];
+        co[6 * (a + 3) + c] = 0;
+        co[6 * (a + 3) + c + 3] = -Sv[3 * a + c];
+      }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += co[6 * a + k] * C.J[6 * k + c];
+        Mx[6 * a + c] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Mx[6 * a + c] += SIw[3 * a + c];
+        Mx[6 * a + c + 3] += C.mass * Sv[3 * a + c];
+        Mx[6 * (a + 3) + c] += C.mass * Sv[3 * a + c];
+      }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += C.Jinv[6 * a + k] * Mx[6 * k + c];
+        P.SA[SAIDX(i, a + 6, b, c + 6)] = (a == c ? 1.0 : 0.0) + dt * s;
+      }
+    // A21 = J^-1 [[0,0],[skew(R^T e3-), 0]] dt   (no m*g: App. C-Q2); zero for SE3Dynamics
+    double Sg[9];
+    if (C.grav != 0.0) {
+      skew(qrot_inv(S.X.q, v3(0, 0, -1.0)), Sg);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) Sg[k] = 0;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += C.Jinv[6 * a + 3 + k] * Sg[3 * k + c];
+        P.SA[SAIDX(i, a + 6, b, c)] = dt * s;
+        P.SA[SAIDX(i, a + 6, b, c + 3)] = 0;
+      }
+  }
+  // ---------------- defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}]  (traopt_controller.py:2882-2888)
+  double d[12];
+  if (ms) {
+    State F = dyn_f<M>(C, S, u);
+    State Sn = load_state(P, src, i + 1, b);
+    V3 dw, dv;
+    se3_log(se3_compose(se3_inverse(Sn.X), F.X), dw, dv);
+    d[0] = dw.x; d[1] = dw.y; d[2] = dw.z; d[3] = dv.x; d[4] = dv.y; d[5] = dv.z;
+    d[6] = F.w.x - Sn.w.x; d[7] = F.w.y - Sn.w.y; d[8] = F.w.z - Sn.w.z;
+    d[9] = F.v.x - Sn.v.x; d[10] = F.v.y - Sn.v.y; d[11] = F.v.z - Sn.v.z;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 12; a++) d[a] = 0;
+  }
+  double d2 = 0;
+#pragma unroll
+  for (int a = 0; a < 12; a++) {
+    P.SA[SAIDX(i, a, b, 12)] = d[a];
+    d2 += d[a] * d[a];
+  }
+  P.SD[(size_t)i * P.Bp + b] = d2;
+}
+
+// per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
+// also the on_iteration bookkeeping of traopt_controller.py:2621-2626
+__global__ void k_reduce(Params P, int it) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp || !P.active[b]) return;
+  double J = 0, d2 = 0;
+  for (int i = 0; i <= P.N; i++) J += P.SC[(size_t)i * P.Bp + b];
+  for (int i = 0; i < P.N; i++) d2 += P.SD[(size_t)i * P.Bp + b];
+  double dn = sqrt(d2);
+  P.Jc[b] = J;
+  P.dn[b] = dn;
+  if (b >= P.B) return;
+  if (it < 0) {
+    if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1)] = dn;
+    return;
+  }
+  if (P.J_hist) P.J_hist[(size_t)b * P.max_iter + it] = J;
+  if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1) + it + 1] = dn;
+  if (P.alpha_hist) P.alpha_hist[(size_t)b * P.max_iter + it] = 1.0;
+  P.iters[b] = it + 1;
+  if (!(J == J) || isinf(J)) { P.status[b] = TOLG_ST_NONFINITE; P.active[b] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: backward Riccati sweep.  16 lanes per trajectory; lane j holds column j of every 12x12
+// (lane 12: the vector column V_x / d / k, lane 13: SS adjoint), rows live in 12 VGPR pairs.
+// C = P^T Q and C = P Q are rank-1 updates whose left factor comes from another lane of the same
+// 16-lane row through DPP row_newbcast, fused into v_fmac_f64 (DP-ALU DPP on gfx90a+).
+// ------------------------------------------------------------------------------------------------
+#ifndef TOLG_DPP_BUILTIN
+#define FM(a, p, q, L) "v_fmac_f64_dpp " a ", " p ", " q " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+// acc[i] += P[k][i] * q   with p = register holding row k of P (column per lane): P^T Q, one k
+TOLG_DEV void rank1_bi(double (&acc)[12], double p, double q) {
+  asm volatile("s_nop 1\n\t" FM("%0", "%12", "%13", 0) FM("%1", "%12", "%13", 1) FM("%2", "%12", "%13", 2)
+                   FM("%3", "%12", "%13", 3) FM("%4", "%12", "%13", 4) FM("%5", "%12", "%13", 5)
+                       FM("%6", "%12", "%13", 6) FM("%7", "%12", "%13", 7) FM("%8", "%12", "%13", 8)
+                           FM("%9", "%12", "%13", 9) FM("%10", "%12", "%13", 10) FM("%11", "%12", "%13", 11)
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
+               : "v"(p), "v"(q));
+}
+#define FMK(a, p, K) "v_fmac_f64_dpp " a ", " p ", %24 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define RANK1_BK(K)                                                                                               \
+  asm volatile("s_nop 1\n\t" FMK("%0", "%12", K) FMK("%1", "%13", K) FMK("%2", "%14", K) FMK("%3", "%15", K)        \
+                   FMK("%4", "%16", K) FMK("%5", "%17", K) FMK("%6", "%18", K) FMK("%7", "%19", K)                 \
+                       FMK("%8", "%20", K) FMK("%9", "%21", K) FMK("%10", "%22", K) FMK("%11", "%23", K)           \
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), \
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])                            \
+               : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(Pm[6]), "v"(Pm[7]),   \
+                 "v"(Pm[8]), "v"(Pm[9]), "v"(Pm[10]), "v"(Pm[11]), "v"(q))
+// acc[i] += P[i][K] * q: P Q, one k (= K); Pm[i] is the register holding row i of P
+template <int K>
+TOLG_DEV void rank1_bk(double (&acc)[12], const double (&Pm)[12], double q) {
+  if constexpr (K == 0) RANK1_BK(0);
+  if constexpr (K == 1) RANK1_BK(1);
+  if constexpr (K == 2) RANK1_BK(2);
+  if constexpr (K == 3) RANK1_BK(3);
+  if constexpr (K == 4) RANK1_BK(4);
+  if constexpr (K == 5) RANK1_BK(5);
+  if constexpr (K == 6) RANK1_BK(6);
+  if constexpr (K == 7) RANK1_BK(7);
+  if constexpr (K == 8) RANK1_BK(8);
+  if constexpr (K == 9) RANK1_BK(9);
+  if constexpr (K == 10) RANK1_BK(10);
+  if constexpr (K == 11) RANK1_BK(11);
+}
+#endif
+
+template <int L>
+TOLG_DEV double bcast(double x) {  // value of x in lane L of this 16-lane row
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, false);
+}
+#ifdef TOLG_DPP_BUILTIN
+TOLG_DEV void rank1_bi(double (&acc)[12], double p, double q) {
+  acc[0] += bcast<0>(p) * q; acc[1] += bcast<1>(p) * q; acc[2] += bcast<2>(p) * q; acc[3] += bcast<3>(p) * q;
+  acc[4] += bcast<4>(p) * q; acc[5] += bcast<5>(p) * q; acc[6] += bcast<6>(p) * q; acc[7] += bcast<7>(p) * q;
+  acc[8] += bcast<8>(p) * q; acc[9] += bcast<9>(p) * q; acc[10] += bcast<10>(p) * q; acc[11] += bcast<11>(p) * q;
+}
+template <int K>
+TOLG_DEV void rank1_bk(double (&acc)[12], const double (&Pm)[12], double q) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) acc[i] += bcast<K>(Pm[i]) * q;
+}
+#endif
+
+template <int M>
+TOLG_DEV bool chol(const double (&S)[M][M], double (&L)[M][M], double (&dinv)[M]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    double d = S[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+    ok = ok && (d > 0.0);
+    double dj = sqrt(ok ? d : 1.0);
+    dinv[j] = 1.0 / dj;
+    L[j][j] = dj;
+#pragma unroll
+    for (int i = j + 1; i < M; i++) {
+      double s = S[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      L[i][j] = s * dinv[j];
+    }
+  }
+  return ok;
+}
+template <int M>
+TOLG_DEV void chol_solve(const double (&L)[M][M], const double (&dinv)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; i++) {
+    double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s * dinv[i];
+  }
+#pragma unroll
+  for (int i = M - 1; i >= 0; i--) {
+    double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; k++) s -= L[k][i] * x[k];
+    x[i] = s * dinv[i];
+  }
+}
+// np.linalg.solve semantics (LU, partial pivoting) for the max-regularisation exit where Q_uu is
+// not PD (traopt_controller.py:2983-2985, :2994-2995).  Branch-free compare-and-swap pivoting.
+template <int M>
+TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
+#pragma unroll
+  for (int c = 0; c < M; c++) {
+#pragma unroll
+    for (int r = c + 1; r < M; r++) {
+      bool sw = fabs(A[r][c]) > fabs(A[c][c]);
+#pragma unroll
+      for (int k = 0; k < M; k++) {
+        double a = A[c][k], bb = A[r][k];
+        A[c][k] = sw ? bb : a;
+        A[r][k] = sw ? a : bb;
+      }
+      double a = x[c], bb = x[r];
+      x[c] = sw ? bb : a;
+      x[r] = sw ? a : bb;
+    }
+    double pinv = 1.0 / A[c][c];
+#pragma unroll
+    for (int r = c + 1; r < M; r++) {
+      double f = A[r][c] * pinv;
+#pragma unroll
+      for (int k = c + 1; k < M; k++) A[r][k] -= f * A[c][k];
+      x[r] -= f * x[c];
+    }
+  }
+#pragma unroll
+  for (int i = M - 1; i >= 0; i--) {
+    double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; k++) s -= A[i][k] * x[k];
+    x[i] = s / A[i][i];
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
+  const Consts& C = *P.c;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
+  const bool act = P.active[b] != 0;
+  if (!__any(act)) return;
+  const int N = P.N;
+  __shared__ double TR[4][12 * 13];
+
+  // lane-dependent constants
+  const double m12 = (j < 12) ? 1.0 : 0.0;                  // matrix columns
+  const double mvec = (j == 12 || j == 13) ? 1.0 : 0.0;     // vector columns (V_x, SS adjoint)
+  const double mA = (j < 13) ? 1.0 : 0.0;
+  double W2col[6], Rcol[M], Bloc[6], Brow[M];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    W2col[r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
+    Bloc[r] = (j < M) ? C.Bc[r * M + j] : 0.0;               // B[6+r][j]
+  }
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    Rcol[u] = (j < M) ? 2.0 * C.R[u * M + j] : 0.0;
+    Brow[u] = (j >= 6 && j < 12) ? C.Bc[(j - 6) * M + u] : 0.0;  // B[j][u]
+  }
+  double mu = P.mu[b], delta = P.delta[b];
+  int warned = 0;
+
+  // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
+  double V[12];
+  {
+    const int c1 = (j < 6) ? j : 6;
+    const double mtop = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      double t1 = P.SL[SLIDX(N, r, b, c1)], t2 = P.SL[SLIDX(N, r, b, 7)];
+      V[r] = mtop * t1;
+      double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
+      V[6 + r] = mvec * t2 + p2;
+    }
+  }
+  double gsum = 0;
+
+  for (int i = N - 1; i >= 0; i--) {
+    // ---- loads: column j of [F_x | d], of [l_xx | l_x], controls
+    double A[12], Lc[12];
+    {
+      const int jj = (j < 13) ? j : 12;
+#pragma unroll
+      for (int r = 0; r < 12; r++) A[r] = mA * P.SA[SAIDX(i, r, b, jj)];
+      const int c1 = (j < 6) ? j : 6;
+      const double mtop = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        double t1 = P.SL[SLIDX(i, r, b, c1)], t2 = P.SL[SLIDX(i, r, b, 7)];
+        Lc[r] = mtop * t1;
+        Lc[6 + r] = mvec * t2 + W2col[r];
+      }
+    }
+    double lu[M];
+    {
+      double uu[M];
+#pragma unroll
+      for (int a = 0; a < M; a++) uu[a] = P.cur_u[UIDX(a, i, b)];
+#pragma unroll
+      for (int a = 0; a < M; a++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) s += 2.0 * C.R[a * M + k] * uu[k];
+        lu[a] = mvec * s;  // l_u = 2 R u rides in the vector columns
+      }
+    }
+    // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
+    double Z[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++) Z[r] = mvec * V[r];
+    // for the adjoint lane (13) A = 0 so Z stays p; for lane 12 A = d.  V_x must not feed the
+    // broadcast side: only lanes 0..11 are ever sources of rank1_bk.
+    rank1_bk<0>(Z, V, A[0]); rank1_bk<1>(Z, V, A[1]); rank1_bk<2>(Z, V, A[2]); rank1_bk<3>(Z, V, A[3]);
+    rank1_bk<4>(Z, V, A[4]); rank1_bk<5>(Z, V, A[5]); rank1_bk<6>(Z, V, A[6]); rank1_bk<7>(Z, V, A[7]);
+    rank1_bk<8>(Z, V, A[8]); rank1_bk<9>(Z, V, A[9]); rank1_bk<10>(Z, V, A[10]); rank1_bk<11>(Z, V, A[11]);
+    // ---- Qh = [l_xx | l_x] + F_x^T Z
+    double Qh[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++) Qh[r] = Lc[r];
+#pragma unroll
+    for (int k = 0; k < 12; k++) rank1_bi(Qh, A[k], Z[k]);
+
+    // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
+    double Quh[M], Kh[M];
+    bool done = !act;  // inactive trajectories skip the loop body but keep EXEC rows uniform
+    bool use_lu = false;
+    double Ls[M][M], dinv[M], Qrep[M][M];
+#pragma unroll
+    for (int u = 0; u < M; u++) { Quh[u] = 0; Kh[u] = 0; dinv[u] = 1; }
+    if (!act) {
+#pragma unroll
+      for (int u = 0; u < M; u++)
+#pragma unroll
+        for (int k = 0; k < M; k++) { Ls[u][k] = (u == k); Qrep[u][k] = (u == k); }
+    }
+    for (;;) {
+      if (!done) {
+        const double muA = m12 * mu;
+        // X' = (V + mu I) F_x, rows 6..11 (B has no other non-zero rows); vector columns: w
+        double Xp[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Xp[k] = Z[6 + k] + muA * A[6 + k];
+        // T = B^T (V + mu I), rows u, column per lane
+        double T[M];
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double s = lu[u], tt = muA * Brow[u];
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            s += C.Bc[k * M + u] * Xp[k];
+            tt += C.Bc[k * M + u] * V[6 + k];
+          }
+          Quh[u] = s;
+          T[u] = m12 * tt;
+        }
+        // Q_uu = 2R + T B: column per lane (lanes 0..M-1), then replicated to every lane
+        double Quu[M];
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double s = Rcol[u];
+          s += bcast<6>(T[u]) * Bloc[0];
+          s += bcast<7>(T[u]) * Bloc[1];
+          s += bcast<8>(T[u]) * Bloc[2];
+          s += bcast<9>(T[u]) * Bloc[3];
+          s += bcast<10>(T[u]) * Bloc[4];
+          s += bcast<11>(T[u]) * Bloc[5];
+          Quu[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          Qrep[u][0] = bcast<0>(Quu[u]); Qrep[u][1] = bcast<1>(Quu[u]);
+          Qrep[u][2] = bcast<2>(Quu[u]); Qrep[u][3] = bcast<3>(Quu[u]);
+          if constexpr (M > 4) { Qrep[u][4] = bcast<4>(Quu[u]); Qrep[u][5] = bcast<5>(Quu[u]); }
+        }
+        // is_pos_def(Q_uu + Q_uu^T)  (traopt_utilis.py:320-329) on the symmetric part
+        double Ssym[M][M];
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int k = 0; k < M; k++) Ssym[u][k] = 0.5 * (Qrep[u][k] + Qrep[k][u]);
+        bool pd = chol<M>(Ssym, Ls, dinv);
+        if (!pd) {
+          delta = fmax(1.0, delta) * 2.0;
+          mu = fmax(1e-6, mu * delta);
+          if (P.max_reg > 0 && mu >= P.max_reg) { warned = 1; use_lu = true; done = true; }
+        } else {
+          delta = fmin(1.0, delta) * 0.5;
+          mu *= delta;
+          if (mu <= 1e-6) mu = 0.0;
+          done = true;
+        }
+      }
+      if (__all(done)) break;
+    }
+    // gradient term: ||Q_u|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
+    {
+      double s = 0;
+#pragma unroll
+      for (int u = 0; u < M; u++) s += Quh[u] * Quh[u];
+      gsum += sqrt(s);
+    }
+    // gains: [K | k] = -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none
+#pragma unroll
+    for (int u = 0; u < M; u++) Kh[u] = (j == 13) ? 0.0 : Quh[u];
+    if (__any(use_lu)) {
+      double Kl[M], Ac[M][M];
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        Kl[u] = Kh[u];
+#pragma unroll
+        for (int k = 0; k < M; k++) Ac[u][k] = Qrep[u][k];
+      }
+      lu_solve<M>(Ac, Kl);
+      chol_solve<M>(Ls, dinv, Kh);
+#pragma unroll
+      for (int u = 0; u < M; u++) Kh[u] = use_lu ? Kl[u] : Kh[u];
+    } else {
+      chol_solve<M>(Ls, dinv, Kh);
+    }
+#pragma unroll
+    for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
+    if (act && j < 13) {
+#pragma unroll
+      for (int u = 0; u < M; u++) P.GK[GKIDX(i, u, b, j)] = Kh[u];
+    }
+    // ---- V <- Qh + Q_ux^T [K | k]   (== Eq. 11b/11c of traopt_controller.py:2998-3003 for the
+    // exact gains), then symmetrise the matrix columns through LDS (traopt_controller.py:3004)
+    double Vn[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++) Vn[r] = Qh[r];
+#pragma unroll
+    for (int u = 0; u < M; u++) rank1_bi(Vn, Quh[u], Kh[u]);
+    __syncthreads();
+    if (j < 12) {
+#pragma unroll
+      for (int r = 0; r < 12; r++) TR[g][r * 13 + j] = Vn[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+      double vt = (j < 12) ? TR[g][j * 13 + r] : Vn[r];
+      V[r] = 0.5 * (Vn[r] + vt);
+    }
+  }
+  // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
+  double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
+  if (act && j == 0) {
+    P.mu[b] = mu;
+    P.delta[b] = delta;
+    P.grad[b] = grad;
+    if (warned) P.status[b] = TOLG_ST_MAXREG;
+    if (it >= 0 && b < P.B) {
+      if (P.grad_hist) P.grad_hist[(size_t)b * (P.max_iter + 1) + it] = grad;
+      if (P.mu_hist && it < P.max_iter) P.mu_hist[(size_t)b * P.max_iter + it] = mu;
+    }
+    if (it >= 0) {
+      bool conv = ms ? (grad < P.tol_grad && P.dn[b] < P.tol_defect) : (grad < P.tol_grad);
+      if (conv) { P.conv[b] = 1; P.active[b] = 0; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: MS closed-loop rollout, one thread per trajectory (traopt_controller.py:2641-2740)
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(64) void k_rollout_ms(Params P, double alpha, int linear) {
+  const Consts& C = *P.c;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.Bp || !P.active[b]) return;
+  const int N = P.N;
+  State Sn = load_state(P, P.cur, 0, b);  // new trajectory, knot i
+  State So = Sn;                          // nominal, knot i
+  store_state(P, P.cand, 0, b, Sn);
+  for (int i = 0; i < N; i++) {
+    State Sx = load_state(P, P.cur, i + 1, b);  // nominal knot i+1
+    // state deviation [Log(q^-1 q_new); xi_new - xi]
+    V3 ew, ev;
+    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+    double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                    Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+    double u[M], un[M], du[M];
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      double s = alpha * P.GK[GKIDX(i, a, b, 12)];
+#pragma unroll
+      for (int k = 0; k < 12; k++) s += P.GK[GKIDX(i, a, b, k)] * e[k];
+      u[a] = P.cur_u[UIDX(a, i, b)];
+      du[a] = s;
+      un[a] = u[a] + s;
+      P.cand_u[UIDX(a, i, b)] = un[a];
+    }
+    double d[12];
+#pragma unroll
+    for (int a = 0; a < 12; a++) d[a] = P.SA[SAIDX(i, a, b, 12)];
+    State Nx;
+    if (!linear) {
+      State Fn = dyn_f<M>(C, Sn, un), Fo = dyn_f<M>(C, So, u);
+      Pose D = se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]));
+      Nx.X = se3_project(se3_compose(se3_compose(se3_compose(Sx.X, D), se3_inverse(Fo.X)), Fn.X));
+      Nx.w = Sx.w + Fn.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
+      Nx.v = Sx.v + Fn.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
+    } else {
+      double lin[12];
+#pragma unroll
+      for (int a = 0; a < 12; a++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) s += P.SA[SAIDX(i, a, b, k)] * e[k];
+        if (a >= 6) {
+#pragma unroll
+          for (int k = 0; k < M; k++) s += C.Bc[(a - 6) * M + k] * du[k];
+        }
+        lin[a] = s;
+      }
+      Pose D = se3_exp(v3(lin[0] + alpha * d[0], lin[1] + alpha * d[1], lin[2] + alpha * d[2]),
+                       v3(lin[3] + alpha * d[3], lin[4] + alpha * d[4], lin[5] + alpha * d[5]));
+      Nx.X = se3_project(se3_compose(Sx.X, D));
+      Nx.w = Sx.w + v3(lin[6] + alpha * d[6], lin[7] + alpha * d[7], lin[8] + alpha * d[8]);
+      Nx.v = Sx.v + v3(lin[9] + alpha * d[9], lin[10] + alpha * d[10], lin[11] + alpha * d[11]);
+    }
+    store_state(P, P.cand, i + 1, b, Nx);
+    Sn = Nx;
+    So = Sx;
+  }
+}
+
+// export kernels for the unit-parity entry point
+__global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restrict__ d, double* __restrict__ lx,
+                             double* __restrict__ lxx11, double* __restrict__ kk, double* __restrict__ K) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.B) return;
+  int b = (int)(t % P.B), i = (int)(t / P.B);
+  size_t bi = (size_t)b * (P.N + 1) + i, bn = (size_t)b * P.N + i;
+  for (int r = 0; r < 6; r++) {
+    if (lxx11) for (int c = 0; c < 6; c++) lxx11[(bi * 6 + r) * 6 + c] = P.SL[SLIDX(i, r, b, c)];
+    if (lx) { lx[bi * 12 + r] = P.SL[SLIDX(i, r, b, 6)]; lx[bi * 12 + 6 + r] = P.SL[SLIDX(i, r, b, 7)]; }
+  }
+  if (i == P.N) return;
+  for (int r = 0; r < 12; r++) {
+    if (Fx) for (int c = 0; c < 12; c++) Fx[(bn * 12 + r) * 12 + c] = P.SA[SAIDX(i, r, b, c)];
+    if (d) d[bn * 12 + r] = P.SA[SAIDX(i, r, b, 12)];
+  }
+  for (int u = 0; u < P.m; u++) {
+    if (K) for (int c = 0; c < 12; c++) K[(bn * P.m + u) * 12 + c] = P.GK[GKIDX(i, u, b, c)];
+    if (kk) kk[bn * P.m + u] = P.GK[GKIDX(i, u, b, 12)];
+  }
+}
+__global__ void k_export_scalars(Params P, double* J, double* dn, double* grad, double* mu_delta, int* iters,
+                                 int* status, int* conv) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  if (J) J[b] = P.Jc[b];
+  if (dn) dn[b] = P.dn[b];
+  if (grad) grad[b] = P.grad[b];
+  if (mu_delta) { mu_delta[2 * b] = P.mu[b]; mu_delta[2 * b + 1] = P.delta[b]; }
+  if (iters) iters[b] = P.iters[b];
+  if (status) status[b] = P.status[b];
+  if (conv) conv[b] = P.conv[b];
+}
+
+}  // namespace tolg
+
+// ================================================================================================
+// host side: handle, workspace carving, C ABI
+// ================================================================================================
+using namespace tolg;
+
+struct tolg_handle_s {
+  tolg_problem prob;
+  Consts hc;
+  int max_batch, Bp_max;
+  char* ws;
+  size_t ws_bytes;
+  Params P;  // pointers carved for Bp_max; per-solve Bp may be smaller (arrays are re-strided)
+  Params run;         // parameters of the solve in flight (tolg_solve_begin .. tolg_solve_end)
+  tolg_options run_opt;
+  int run_it;         // iterations issued so far
+  bool running;
+  // timing
+  bool timing;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> ev_kind;    // 0 backward, 1 rollout, 2 linearize
+  size_t ev_used;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int host_inv6(const double A[36], double Ai[36]) {
+  double Mx[6][12];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { Mx[i][j] = A[6 * i + j]; Mx[i][j + 6] = (i == j); }
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    for (int r = c + 1; r < 6; r++) if (fabs(Mx[r][c]) > fabs(Mx[p][c])) p = r;
+    if (Mx[p][c] == 0) return -1;
+    if (p != c) for (int j = 0; j < 12; j++) { double t = Mx[c][j]; Mx[c][j] = Mx[p][j]; Mx[p][j] = t; }
+    double d = Mx[c][c];
+    for (int j = 0; j < 12; j++) Mx[c][j] /= d;
+    for (int r = 0; r < 6; r++) if (r != c) {
+      double f = Mx[r][c];
+      if (f != 0) for (int j = 0; j < 12; j++) Mx[r][j] -= f * Mx[c][j];
+    }
+  }
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Ai[6 * i + j] = Mx[i][j + 6];
+  return 0;
+}
+
+struct Carve {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, Consts** dc) {
+  Carve c{base, 0};
+  size_t N = (size_t)pr->N, m = (size_t)pr->m, B = (size_t)Bp;
+  Consts* cc = c.take<Consts>(1);
+  double* ref = c.take<double>((N + 1) * 13);
+  double* cur = c.take<double>(13 * (N + 1) * B);
+  double* cur_u = c.take<double>(m * N * B);
+  double* cand = c.take<double>(13 * (N + 1) * B);
+  double* cand_u = c.take<double>(m * N * B);
+  double* SA = c.take<double>(N * 12 * B * 13);
+  double* SL = c.take<double>((N + 1) * 6 * B * 8);
+  double* SC = c.take<double>((N + 1) * B);
+  double* SD = c.take<double>(N * B);
+  double* GK = c.take<double>(N * m * B * 13);
+  double* mu = c.take<double>(B);
+  double* delta = c.take<double>(B);
+  double* Jc = c.take<double>(B);
+  double* dn = c.take<double>(B);
+  double* grad = c.take<double>(B);
+  int* active = c.take<int>(B);
+  int* iters = c.take<int>(B);
+  int* status = c.take<int>(B);
+  int* conv = c.take<int>(B);
+  if (P) {
+    P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
+    P->SA = SA; P->SL = SL; P->SC = SC; P->SD = SD; P->GK = GK; P->mu = mu; P->delta = delta; P->Jc = Jc;
+    P->dn = dn; P->grad = grad; P->active = active; P->iters = iters; P->status = status; P->conv = conv;
+  }
+  if (dc) *dc = cc;
+  return align_up(c.off, 256);
+}
+
+static int check_problem(const tolg_problem* p) {
+  if (!p) return TOLG_E_ARG;
+  if (p->N < 1 || !(p->dt > 0)) return TOLG_E_ARG;
+  if (p->kind == TOLG_DYN_DRONE) { if (p->m != 4) return TOLG_E_ARG; }
+  else if (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_RIGIDBODY) { if (p->m != 6) return TOLG_E_ARG; }
+  else return TOLG_E_ARG;
+  return 0;
+}
+
+extern "C" size_t tolg_workspace_bytes(const tolg_problem* prob, int32_t max_batch) {
+  if (check_problem(prob) || max_batch < 1) return 0;
+  int Bp = (max_batch + 3) / 4 * 4;
+  return carve_all(prob, Bp, nullptr, nullptr, nullptr);
+}
+
+extern "C" const char* tolg_version(void) { return "tolg-hip 0.1 (gfx950)"; }
+
+#define LAUNCH_CHECK()                                         \
+  do {                                                         \
+    hipError_t e_ = hipGetLastError();                         \
+    if (e_ != hipSuccess) {                                    \
+      fprintf(stderr, "tolg: launch failed at %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return TOLG_E_LAUNCH;                                    \
+    }                                                          \
+  } while (0)
+
+extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, const double* d_xi_ref,
+                           int32_t max_batch, void* d_workspace, size_t workspace_bytes, void* stream,
+                           tolg_handle_t* out) {
+  if (check_problem(prob) || !d_q_ref || !d_xi_ref || !d_workspace || !out || max_batch < 1) return TOLG_E_ARG;
+  if (workspace_bytes < tolg_workspace_bytes(prob, max_batch)) return TOLG_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) != 0) return TOLG_E_ARG;
+  tolg_handle_s* h = new (std::nothrow) tolg_handle_s();
+  if (!h) return TOLG_E_ARG;
+  h->prob = *prob;
+  h->max_batch = max_batch;
+  h->Bp_max = (max_batch + 3) / 4 * 4;
+  h->ws = static_cast<char*>(d_workspace);
+  h->ws_bytes = workspace_bytes;
+  h->timing = false;
+  h->ev_used = 0;
+  h->running = false;
+  h->run_it = 0;
+  Consts& c = h->hc;
+  memset(&c, 0, sizeof c);
+  c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.dt = prob->dt;
+  memcpy(c.J, prob->J, sizeof c.J);
+  if (host_inv6(prob->J, c.Jinv)) { delete h; return TOLG_E_SINGULAR; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.Ib[3 * i + j] = prob->J[6 * i + j];
+  c.mass = prob->J[6 * 4 + 4];                      // traopt_dynamics.py:663
+  c.grav = (prob->kind == TOLG_DYN_SE3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      c.W1[6 * i + j] = prob->Q[12 * i + j];
+      c.W2[6 * i + j] = prob->Q[12 * (i + 6) + j + 6];
+      c.P1[6 * i + j] = prob->P[12 * i + j];
+      c.P2[6 * i + j] = prob->P[12 * (i + 6) + j + 6];
+    }
+  int m = prob->m;
+  for (int i = 0; i < m * m; i++) c.R[i] = prob->R[i];
+  if (prob->kind == TOLG_DYN_DRONE) {  // traopt_dynamics.py:1250-1254
+    c.Pu[0 * 4 + 0] = 1; c.Pu[1 * 4 + 1] = 1; c.Pu[2 * 4 + 2] = 1; c.Pu[5 * 4 + 3] = 1;
+  } else {
+    for (int i = 0; i < 6; i++) c.Pu[i * 6 + i] = 1;
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < m; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += c.Jinv[6 * i + k] * c.Pu[k * m + j];
+      c.Bc[i * m + j] = s * prob->dt;  // F_u = Bt dt (traopt_dynamics.py:668-670, :850)
+    }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Consts* dc = nullptr;
+  memset(&h->P, 0, sizeof h->P);
+  carve_all(prob, h->Bp_max, h->ws, &h->P, &dc);
+  h->P.N = prob->N; h->P.m = prob->m;
+  if (hipMemcpyAsync(dc, &h->hc, sizeof(Consts), hipMemcpyHostToDevice, st) != hipSuccess) { delete h; return TOLG_E_LAUNCH; }
+  int N = prob->N;
+  hipLaunchKernelGGL(k_pack_ref, dim3((N + 1 + 63) / 64), dim3(64), 0, st, N, d_q_ref, d_xi_ref,
+                     const_cast<double*>(h->P.ref));
+  LAUNCH_CHECK();
+  *out = h;
+  return 0;
+}
+
+extern "C" void tolg_destroy(tolg_handle_t h) {
+  if (!h) return;
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+extern "C" void tolg_enable_timing(tolg_handle_t h, int32_t on) {
+  if (!h) return;
+  h->timing = on != 0;
+  if (h->timing && h->ev.empty()) {
+    h->ev.resize(2 * 4096);
+    for (auto& e : h->ev) (void)hipEventCreate(&e);
+    h->ev_kind.resize(4096);
+  }
+  h->ev_used = 0;
+}
+
+namespace {
+struct Timed {
+  tolg_handle_s* h; hipStream_t st; int kind; bool on;
+  Timed(tolg_handle_s* h_, hipStream_t s, int k) : h(h_), st(s), kind(k) {
+    on = h->timing && h->ev_used < h->ev_kind.size();
+    if (on) (void)hipEventRecord(h->ev[2 * h->ev_used], st);
+  }
+  ~Timed() {
+    if (on) { (void)hipEventRecord(h->ev[2 * h->ev_used + 1], st); h->ev_kind[h->ev_used] = kind; h->ev_used++; }
+  }
+};
+}  // namespace
+
+extern "C" int tolg_kernel_time(tolg_handle_t h, int32_t reset, double* ms_backward, double* ms_rollout,
+                                double* ms_linearize, int64_t* launches) {
+  if (!h) return TOLG_E_ARG;
+  double acc[3] = {0, 0, 0};
+  int64_t nb = 0;
+  for (size_t i = 0; i < h->ev_used; i++) {
+    (void)hipEventSynchronize(h->ev[2 * i + 1]);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) acc[h->ev_kind[i]] += ms;
+    if (h->ev_kind[i] == 0) nb++;
+  }
+  if (ms_backward) *ms_backward = acc[0];
+  if (ms_rollout) *ms_rollout = acc[1];
+  if (ms_linearize) *ms_linearize = acc[2];
+  if (launches) *launches = nb;
+  if (reset) h->ev_used = 0;
+  return 0;
+}
+
+static Params params_for(tolg_handle_s* h, int B) {
+  Params P = h->P;
+  P.B = B;
+  P.Bp = (B + 3) / 4 * 4;
+  P.J_hist = P.grad_hist = P.defect_hist = P.alpha_hist = P.mu_hist = nullptr;
+  P.max_iter = 0; P.tol_grad = 0; P.tol_defect = 0; P.max_reg = 1e10;
+  return P;
+}
+
+template <int M>
+static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, const double* src, const double* src_u,
+                         double* dst, double* dst_u, int ms) {
+  size_t n = (size_t)(P.N + 1) * P.Bp;
+  Timed t(h, st, 2);
+  hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms);
+  LAUNCH_CHECK();
+  return 0;
+}
+template <int M>
+static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
+  Timed t(h, st, 0);
+  hipLaunchKernelGGL(k_backward<M>, dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+  LAUNCH_CHECK();
+  return 0;
+}
+template <int M>
+static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear) {
+  Timed t(h, st, 1);
+  hipLaunchKernelGGL(k_rollout_ms<M>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, alpha, linear);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+template <int M>
+static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+  int rc;
+  for (int it = it0; it < it0 + n; it++) {
+    if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
+    if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
+    // the accepted candidate becomes the nominal trajectory while it is re-linearised
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
+                                const double* d_x0_xi, const double* d_us_init, double* d_J_hist,
+                                double* d_grad_hist, double* d_defect_hist, double* d_alpha_hist, double* d_mu_hist,
+                                void* stream) {
+  if (!h || !opt || B < 1 || B > h->max_batch || !d_x0_q || !d_x0_xi || !d_us_init) return TOLG_E_ARG;
+  if (opt->max_iter < 0) return TOLG_E_ARG;
+  if (opt->mode != TOLG_MODE_MS) return TOLG_E_ARG;  // SS arrives with the speculative line search
+  if (opt->line_search) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Params P = params_for(h, B);
+  P.J_hist = d_J_hist; P.grad_hist = d_grad_hist; P.defect_hist = d_defect_hist; P.alpha_hist = d_alpha_hist;
+  P.mu_hist = d_mu_hist; P.max_iter = opt->max_iter; P.tol_grad = opt->tol_grad; P.tol_defect = opt->tol_defect;
+  P.max_reg = opt->max_reg;
+  size_t n = (size_t)(P.N + 1) * P.Bp;
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, 1);
+  LAUNCH_CHECK();
+  int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 1)
+                      : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, -1);
+  LAUNCH_CHECK();
+  h->run = P; h->run_opt = *opt; h->run_it = 0; h->running = true;
+  return 0;
+}
+
+extern "C" int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream) {
+  if (!h || !h->running || n_iter < 0) return TOLG_E_ARG;
+  if (h->run_it + n_iter > h->run_opt.max_iter) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = (h->run.m == 4) ? iterate_ms<4>(h, h->run, &h->run_opt, st, h->run_it, n_iter)
+                           : iterate_ms<6>(h, h->run, &h->run_opt, st, h->run_it, n_iter);
+  if (rc) return rc;
+  h->run_it += n_iter;
+  return 0;
+}
+
+extern "C" int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                              int32_t* d_status, int32_t* d_converged, void* stream) {
+  if (!h || !h->running) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Params& P = h->run;
+  size_t n = (size_t)(P.N + 1) * P.Bp;
+  hipLaunchKernelGGL(k_unpack_traj, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, P.cur, P.cur_u, d_xs_q,
+                     d_xs_xi, d_us);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_export_scalars, dim3((P.B + 63) / 64), dim3(64), 0, st, P, nullptr, nullptr, nullptr, nullptr,
+                     d_iters, d_status, d_converged);
+  LAUNCH_CHECK();
+  h->running = false;
+  return 0;
+}
+
+extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
+                                const double* d_x0_xi, const double* d_us_init, double* d_xs_q, double* d_xs_xi,
+                                double* d_us, double* d_J_hist, double* d_grad_hist, double* d_defect_hist,
+                                double* d_alpha_hist, double* d_mu_hist, int32_t* d_iters, int32_t* d_status,
+                                int32_t* d_converged, void* stream) {
+  int rc = tolg_solve_begin(h, opt, B, d_x0_q, d_x0_xi, d_us_init, d_J_hist, d_grad_hist, d_defect_hist, d_alpha_hist,
+                            d_mu_hist, stream);
+  if (rc) return rc;
+  if ((rc = tolg_solve_iterate(h, opt->max_iter, stream))) return rc;
+  return tolg_solve_end(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream);
+}
+
+extern "C" int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_reg, int32_t B, const double* d_xs_q,
+                                       const double* d_xs_xi, const double* d_us, double* d_mu_delta, double* d_Fx,
+                                       double* d_d, double* d_lx, double* d_lxx11, double* d_k, double* d_K,
+                                       double* d_J, double* d_dnorm, double* d_grad, void* stream) {
+  if (!h || B < 1 || B > h->max_batch || !d_xs_q || !d_xs_xi || !d_us) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Params P = params_for(h, B);
+  P.max_reg = max_reg;
+  size_t n = (size_t)(P.N + 1) * P.Bp;
+  hipLaunchKernelGGL(k_pack_traj, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_xs_q, d_xs_xi, d_us,
+                     (const double*)d_mu_delta);
+  LAUNCH_CHECK();
+  int rc;
+  if (P.m == 4) {
+    if ((rc = run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms))) return rc;
+  } else {
+    if ((rc = run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms))) return rc;
+  }
+  hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, -1);
+  LAUNCH_CHECK();
+  if ((rc = (P.m == 4) ? run_backward<4>(h, P, st, -1, ms) : run_backward<6>(h, P, st, -1, ms))) return rc;
+  size_t ne = (size_t)(P.N + 1) * B;
+  hipLaunchKernelGGL(k_export_lin, dim3((unsigned)((ne + 127) / 128)), dim3(128), 0, st, P, d_Fx, d_d, d_lx, d_lxx11,
+                     d_k, d_K);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_export_scalars, dim3((B + 63) / 64), dim3(64), 0, st, P, d_J, d_dnorm, d_grad, d_mu_delta,
+                     nullptr, nullptr, nullptr);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear, double alpha, int32_t B,
+                            double* d_xs_q_new, double* d_xs_xi_new, double* d_us_new, void* stream) {
+  if (!h || B < 1 || B > h->max_batch) return TOLG_E_ARG;
+  if (!ms) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Params P = params_for(h, B);
+  int rc = (P.m == 4) ? run_rollout_ms<4>(h, P, st, alpha, rollout_linear) : run_rollout_ms<6>(h, P, st, alpha, rollout_linear);
+  if (rc) return rc;
+  size_t n = (size_t)(P.N + 1) * P.Bp;
+  hipLaunchKernelGGL(k_unpack_traj, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, P.cand, P.cand_u, d_xs_q_new,
+                     d_xs_xi_new, d_us_new);
+  LAUNCH_CHECK();
+  return 0;
+}

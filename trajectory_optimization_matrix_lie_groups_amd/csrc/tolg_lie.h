@@ -1,0 +1,223 @@
+// tolg_lie.h -- SO(3)/SE(3) device math for the gfx950 kernels (fp64, registers only).
+//
+// Semantics follow what the reference obtains from manifpy at its call sites
+// (traoptlibrary/traopt_dynamics.py:783,823; traopt_cost.py:668,778; traopt_controller.py:2683,
+// 2714,2804): unit-quaternion + translation poses, Exp/Log, rplus/lminus/rminus and their
+// Jacobians in the library's [omega, v] twist order (traoptlibrary/traopt_utilis.py:43-92,387-399).
+// Poses never exist as 4x4 matrices on the device: a pose is (unit quaternion xyzw, translation),
+// which is also what the reference's arithmetic runs on (every 4x4 it holds is re-derived from a
+// unit quaternion, traopt_utilis.py:331-354), so results agree to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define TOLG_DEV __device__ __forceinline__
+#define TOLG_EPS 1e-10  // manif Constants<double>::eps (small-angle switch)
+
+namespace tolg {
+
+struct V3 { double x, y, z; };
+struct Q4 { double x, y, z, w; };
+struct Pose { Q4 q; V3 t; };
+
+TOLG_DEV V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+TOLG_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TOLG_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TOLG_DEV V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+TOLG_DEV V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+TOLG_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+TOLG_DEV V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+TOLG_DEV Q4 qmul(Q4 a, Q4 b) {
+  Q4 r;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return r;
+}
+TOLG_DEV Q4 qconj(Q4 a) { Q4 r; r.x = -a.x; r.y = -a.y; r.z = -a.z; r.w = a.w; return r; }
+TOLG_DEV Q4 qnormalize(Q4 a) {
+  double s = 1.0 / sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  Q4 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; r.w = a.w * s; return r;
+}
+// R(q) v for a unit quaternion
+TOLG_DEV V3 qrot(Q4 q, V3 v) {
+  V3 u = v3(q.x, q.y, q.z);
+  V3 t = 2.0 * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+TOLG_DEV V3 qrot_inv(Q4 q, V3 v) { return qrot(qconj(q), v); }
+// row-major rotation matrix of a unit quaternion (Eigen toRotationMatrix)
+TOLG_DEV void q_to_R(Q4 q, double R[9]) {
+  double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+// scipy Rotation.from_matrix(...).as_quat() (traopt_utilis.py:167-181): the projection the
+// reference applies to every 4x4 it touches.
+TOLG_DEV Q4 R_to_q(const double R[9]) {
+  double tr = R[0] + R[4] + R[8];
+  double qx, qy, qz, qw;
+  if (tr >= R[0] && tr >= R[4] && tr >= R[8]) {
+    qx = R[7] - R[5]; qy = R[2] - R[6]; qz = R[3] - R[1]; qw = 1 + tr;
+  } else if (R[0] >= R[4] && R[0] >= R[8]) {
+    qx = 1 - tr + 2 * R[0]; qy = R[3] + R[1]; qz = R[6] + R[2]; qw = R[7] - R[5];
+  } else if (R[4] >= R[8]) {
+    qy = 1 - tr + 2 * R[4]; qz = R[7] + R[5]; qx = R[1] + R[3]; qw = R[2] - R[6];
+  } else {
+    qz = 1 - tr + 2 * R[8]; qx = R[2] + R[6]; qy = R[5] + R[7]; qw = R[3] - R[1];
+  }
+  Q4 q; q.x = qx; q.y = qy; q.z = qz; q.w = qw;
+  return qnormalize(q);
+}
+
+// Coefficients of V(w) = Jl(w) = I + a W + b W^2 and of the SE(3) Q block (Barfoot 7.86).
+struct SO3Coef { double a, b, c1, c2, c3; };
+TOLG_DEV SO3Coef so3_coef(double th2, bool want_q) {
+  SO3Coef k;
+  if (th2 <= TOLG_EPS) {
+    k.a = 0.5; k.b = 0.0;  // manif small-angle ljac: I + W/2
+    k.c1 = 1.0 / 6 - th2 / 120; k.c2 = 1.0 / 24 - th2 / 720; k.c3 = 1.0 / 120 - th2 / 2520;
+  } else {
+    double th = sqrt(th2), s, c;
+    sincos(th, &s, &c);
+    double i2 = 1.0 / th2;
+    k.a = (1 - c) * i2;
+    k.b = (th - s) * i2 / th;
+    if (want_q) {
+      k.c1 = k.b;
+      k.c2 = (th2 + 2 * c - 2) * (0.5 * i2 * i2);
+      k.c3 = (2 * th - 3 * s + th * c) * (0.5 * i2 * i2 / th);
+    } else {
+      k.c1 = k.c2 = k.c3 = 0;
+    }
+  }
+  return k;
+}
+// manif SO3Tangent::exp -> unit quaternion
+TOLG_DEV Q4 so3_exp(V3 w) {
+  double th2 = dot(w, w);
+  Q4 q;
+  if (th2 > TOLG_EPS) {
+    double th = sqrt(th2), s, c;
+    sincos(0.5 * th, &s, &c);
+    s /= th;
+    q.x = s * w.x; q.y = s * w.y; q.z = s * w.z; q.w = c;
+  } else {
+    q.x = 0.5 * w.x; q.y = 0.5 * w.y; q.z = 0.5 * w.z; q.w = 1.0;
+    q = qnormalize(q);
+  }
+  return q;
+}
+// manif SO3::log (sign-fixed, quaternion based)
+TOLG_DEV V3 so3_log(Q4 q) {
+  double s2 = q.x * q.x + q.y * q.y + q.z * q.z, c;
+  if (s2 > TOLG_EPS) {
+    double s = sqrt(s2);
+    double two = 2.0 * ((q.w < 0.0) ? atan2(-s, -q.w) : atan2(s, q.w));
+    c = two / s;
+  } else {
+    // q and -q are the same rotation.  The reference only ever takes Log of quaternions that scipy
+    // just derived from a matrix (w > 0 near the identity); here quaternions are composed directly,
+    // so the small-angle branch has to pick the w > 0 representative itself.
+    c = (q.w < 0.0) ? -2.0 : 2.0;
+  }
+  return v3(c * q.x, c * q.y, c * q.z);
+}
+// V(w) v with precomputed coefficients
+TOLG_DEV V3 ljac_apply(V3 w, SO3Coef k, V3 v) {
+  V3 wv = cross(w, v);
+  return v + k.a * wv + k.b * cross(w, wv);
+}
+// coefficient of W^2 in V(w)^-1 = I - W/2 + c W^2
+TOLG_DEV double ljacinv_coef(double th2) {
+  if (th2 <= TOLG_EPS) return 0.0;
+  double th = sqrt(th2), s, c;
+  sincos(th, &s, &c);
+  return 1.0 / th2 - (1 + c) / (2 * th * s);
+}
+TOLG_DEV V3 ljacinv_apply(V3 w, double c, V3 v) {
+  V3 wv = cross(w, v);
+  return v - 0.5 * wv + c * cross(w, wv);
+}
+
+TOLG_DEV Pose se3_exp(V3 w, V3 v) {
+  Pose X;
+  X.q = so3_exp(w);
+  X.t = ljac_apply(w, so3_coef(dot(w, w), false), v);
+  return X;
+}
+TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
+  w = so3_log(X.q);
+  v = ljacinv_apply(w, ljacinv_coef(dot(w, w)), X.t);
+}
+TOLG_DEV Pose se3_compose(Pose A, Pose B) {
+  Pose C;
+  C.q = qmul(A.q, B.q);
+  C.t = A.t + qrot(A.q, B.t);
+  return C;
+}
+TOLG_DEV Pose se3_inverse(Pose A) {
+  Pose B;
+  B.q = qconj(A.q);
+  B.t = neg(qrot(B.q, A.t));
+  return B;
+}
+// the reference re-derives a unit quaternion from every matrix it receives: renormalise
+TOLG_DEV Pose se3_project(Pose A) { A.q = qnormalize(A.q); return A; }
+
+// ---- 3x3 helpers (row-major, fully unrolled so they stay in registers) ----------------------
+TOLG_DEV void skew(V3 w, double S[9]) {
+  S[0] = 0;    S[1] = -w.z; S[2] = w.y;
+  S[3] = w.z;  S[4] = 0;    S[5] = -w.x;
+  S[6] = -w.y; S[7] = w.x;  S[8] = 0;
+}
+TOLG_DEV void mul33(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// Jl(w) as a matrix
+TOLG_DEV void ljac33(V3 w, SO3Coef k, double J[9]) {
+  double W[9], W2[9];
+  skew(w, W);
+  mul33(W, W, W2);
+#pragma unroll
+  for (int i = 0; i < 9; i++) J[i] = k.a * W[i] + k.b * W2[i];
+  J[0] += 1; J[4] += 1; J[8] += 1;
+}
+TOLG_DEV void ljacinv33(V3 w, double c, double J[9]) {
+  double W[9], W2[9];
+  skew(w, W);
+  mul33(W, W, W2);
+#pragma unroll
+  for (int i = 0; i < 9; i++) J[i] = -0.5 * W[i] + c * W2[i];
+  J[0] += 1; J[4] += 1; J[8] += 1;
+}
+// Barfoot Q(rho, theta) with coefficients of |theta|
+TOLG_DEV void Q33(V3 rho, V3 th, SO3Coef k, double Q[9]) {
+  double P[9], W[9], WP[9], PW[9], WPW[9], WWP[9], PWW[9], WPWW[9], WWPW[9];
+  skew(rho, P);
+  skew(th, W);
+  mul33(W, P, WP);
+  mul33(P, W, PW);
+  mul33(WP, W, WPW);
+  mul33(W, WP, WWP);
+  mul33(PW, W, PWW);
+  mul33(WPW, W, WPWW);
+  mul33(W, WPW, WWPW);
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+    Q[i] = 0.5 * P[i] + k.c1 * (WP[i] + PW[i] + WPW[i]) + k.c2 * (WWP[i] + PWW[i] - 3 * WPW[i]) +
+           k.c3 * (WPWW[i] + WWPW[i]);
+}
+
+}  // namespace tolg

@@ -1,0 +1,225 @@
+"""Host side of the batched solver: PyTorch-ROCm tensors in, C ABI (include/tolg.h) underneath.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); every flop of the hot path
+runs in the hand-written HIP kernels of csrc/tolg_kernels.hip.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+
+_KIND = {"se3": _capi.DYN_SE3, "rigidbody": _capi.DYN_RIGIDBODY, "drone": _capi.DYN_DRONE}
+
+
+@dataclass
+class TrackingProblem:
+    """One (dynamics, cost) pair shared by the batch.
+
+    Mirrors the constructor arguments of SE3Dynamics / RigidBodyDynamics / DroneDynamics
+    (reference traoptlibrary/traopt_dynamics.py:633, :906, :1214) and
+    SE3TrackingQuadraticGaussNewtonCost (traoptlibrary/traopt_cost.py:587)."""
+    kind: str
+    J: np.ndarray
+    dt: float
+    Q: np.ndarray
+    R: np.ndarray
+    P: np.ndarray
+    q_ref: np.ndarray   # (N+1, 4, 4)
+    xi_ref: np.ndarray  # (N+1, 6)
+
+    @property
+    def N(self):
+        return int(np.asarray(self.q_ref).shape[0]) - 1
+
+    @property
+    def m(self):
+        return 4 if self.kind == "drone" else 6
+
+
+@dataclass
+class FitResult:
+    xs_q: torch.Tensor      # [B, N+1, 4, 4]
+    xs_xi: torch.Tensor     # [B, N+1, 6]
+    us: torch.Tensor        # [B, N, m]
+    J_hist: torch.Tensor    # [B, max_iter]
+    grad_hist: torch.Tensor  # [B, max_iter+1]
+    defect_hist: torch.Tensor  # [B, max_iter+1]
+    alpha_hist: torch.Tensor
+    mu_hist: torch.Tensor
+    iters: torch.Tensor     # [B] int32
+    status: torch.Tensor    # [B] int32
+    converged: torch.Tensor  # [B] int32
+    extra: dict = field(default_factory=dict)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class BatchedTrackingILQR:
+    """Batched iLQR_Tracking_SE3_MS / iLQR_Tracking_SE3 on one GPU (one process per GPU).
+
+    The object owns a device workspace tensor (allocated once, here) and an opaque C handle; the
+    solve calls allocate nothing inside the library."""
+
+    def __init__(self, problem: TrackingProblem, max_batch: int, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the batched solver is HIP-only (there is no CPU fallback)")
+        self.lib = _capi.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.problem = problem
+        self.N, self.m = problem.N, problem.m
+        self.max_batch = int(max_batch)
+        p = _capi.Problem()
+        p.kind, p.m, p.N, p.dt = _KIND[problem.kind], self.m, self.N, float(problem.dt)
+        p.J[:] = list(np.asarray(problem.J, dtype=np.float64).reshape(36))
+        p.Q[:] = list(np.asarray(problem.Q, dtype=np.float64).reshape(144))
+        p.P[:] = list(np.asarray(problem.P, dtype=np.float64).reshape(144))
+        Rm = np.zeros(36)
+        Rm[: self.m * self.m] = np.asarray(problem.R, dtype=np.float64).reshape(-1)
+        p.R[:] = list(Rm)
+        self._p = p
+        nbytes = self.lib.tolg_workspace_bytes(C.byref(p), self.max_batch)
+        if nbytes == 0:
+            raise ValueError("invalid problem description")
+        self.workspace_bytes = int(nbytes)
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self._ws.data_ptr()) % 256
+            self._ws_ptr = self._ws.data_ptr() + off
+            self._q_ref = torch.as_tensor(np.ascontiguousarray(problem.q_ref, dtype=np.float64).reshape(self.N + 1, 16),
+                                          device=self.device)
+            self._xi_ref = torch.as_tensor(np.ascontiguousarray(problem.xi_ref, dtype=np.float64).reshape(self.N + 1, 6),
+                                           device=self.device)
+            h = C.c_void_p()
+            rc = self.lib.tolg_create(C.byref(p), _ptr(self._q_ref), _ptr(self._xi_ref), self.max_batch,
+                                      C.c_void_p(self._ws_ptr), C.c_size_t(nbytes), self._stream(), C.byref(h))
+        _capi.check(rc, "tolg_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
+            self.lib.tolg_destroy(h)
+            self._h = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, shape):
+        t = torch.as_tensor(a, dtype=torch.float64, device=self.device)
+        return t.reshape(shape).contiguous()
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc_result(self, B, K, histories=True):
+        f64 = dict(dtype=torch.float64, device=self.device)
+        nanf = lambda *shape: torch.full(shape, float("nan"), **f64) if histories else None  # noqa: E731
+        return FitResult(
+            xs_q=torch.empty(B, self.N + 1, 4, 4, **f64), xs_xi=torch.empty(B, self.N + 1, 6, **f64),
+            us=torch.empty(B, self.N, self.m, **f64), J_hist=nanf(B, K), grad_hist=nanf(B, K + 1),
+            defect_hist=nanf(B, K + 1), alpha_hist=nanf(B, K), mu_hist=nanf(B, K),
+            iters=torch.zeros(B, dtype=torch.int32, device=self.device),
+            status=torch.zeros(B, dtype=torch.int32, device=self.device),
+            converged=torch.zeros(B, dtype=torch.int32, device=self.device))
+
+    def solve_begin(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
+                    tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10, histories=True,
+                    out: Optional[FitResult] = None) -> FitResult:
+        """_initial_guess + first _linearization; leaves the batch resident in HBM."""
+        x0_q = self._dev(x0_q, (-1, 16))
+        B = x0_q.shape[0]
+        x0_xi = self._dev(x0_xi, (B, 6))
+        if us_init is None:
+            us_init = torch.zeros(B, self.N, self.m, dtype=torch.float64, device=self.device)
+        us_init = self._dev(us_init, (B, self.N, self.m))
+        K = int(n_iterations)
+        if out is None:
+            out = self._alloc_result(B, K, histories)
+        o = _capi.Options(_capi.MODE_MS if mode == "ms" else _capi.MODE_SS, K, int(bool(line_search)),
+                          int(rollout == "linear"), float(tol_grad_norm), float(tol_d_norm),
+                          float(max_reg if max_reg else 0.0))
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_begin(self._h, C.byref(o), B, _ptr(x0_q), _ptr(x0_xi), _ptr(us_init),
+                                           _ptr(out.J_hist), _ptr(out.grad_hist), _ptr(out.defect_hist),
+                                           _ptr(out.alpha_hist), _ptr(out.mu_hist), self._stream())
+        _capi.check(rc, "tolg_solve_begin")
+        self._inflight = (out, (x0_q, x0_xi, us_init))  # keep the inputs alive until the stream has used them
+        return out
+
+    def solve_iterate(self, n_iter):
+        """n_iter passes of the iteration body (backward sweep, rollout, re-linearisation)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_iterate(self._h, int(n_iter), self._stream())
+        _capi.check(rc, "tolg_solve_iterate")
+
+    def solve_end(self) -> FitResult:
+        out = self._inflight[0]
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_end(self._h, _ptr(out.xs_q), _ptr(out.xs_xi), _ptr(out.us), _ptr(out.iters),
+                                         _ptr(out.status), _ptr(out.converged), self._stream())
+        _capi.check(rc, "tolg_solve_end")
+        return out
+
+    def fit_batch(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
+                  tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10,
+                  histories=True, out: Optional[FitResult] = None) -> FitResult:
+        """B independent fits (the reference's joblib fan-out, visualization/perturb_all_compute.py:240).
+        Inputs may be numpy arrays or tensors already on the device; outputs are device tensors."""
+        self.solve_begin(x0_q, x0_xi, us_init, mode, n_iterations, tol_grad_norm, tol_d_norm, line_search, rollout,
+                         max_reg, histories, out)
+        self.solve_iterate(n_iterations)
+        return self.solve_end()
+
+    # ------------------------------------------------------------------------------------------
+    def linearize_backward(self, xs_q, xs_xi, us, ms=True, mu=1.0, delta=2.0, max_reg=1e10):
+        """One _linearization + _backward_pass (+ gradient norm) on given trajectories."""
+        xs_q = self._dev(xs_q, (-1, self.N + 1, 16))
+        B = xs_q.shape[0]
+        xs_xi = self._dev(xs_xi, (B, self.N + 1, 6))
+        us = self._dev(us, (B, self.N, self.m))
+        f64 = dict(dtype=torch.float64, device=self.device)
+        md = torch.empty(B, 2, **f64)
+        md[:, 0] = mu
+        md[:, 1] = delta
+        r = dict(Fx=torch.empty(B, self.N, 12, 12, **f64), d=torch.empty(B, self.N, 12, **f64),
+                 lx=torch.empty(B, self.N + 1, 12, **f64), lxx11=torch.empty(B, self.N + 1, 6, 6, **f64),
+                 k=torch.empty(B, self.N, self.m, **f64), K=torch.empty(B, self.N, self.m, 12, **f64),
+                 J=torch.empty(B, **f64), dnorm=torch.empty(B, **f64), grad=torch.empty(B, **f64), mu_delta=md)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_linearize_backward(self._h, int(ms), float(max_reg), B, _ptr(xs_q), _ptr(xs_xi), _ptr(us),
+                                                  _ptr(md), _ptr(r["Fx"]), _ptr(r["d"]), _ptr(r["lx"]), _ptr(r["lxx11"]),
+                                                  _ptr(r["k"]), _ptr(r["K"]), _ptr(r["J"]), _ptr(r["dnorm"]),
+                                                  _ptr(r["grad"]), self._stream())
+        _capi.check(rc, "tolg_linearize_backward")
+        return r
+
+    def rollout(self, B, alpha=1.0, ms=True, rollout="nonlinear"):
+        """Closed-loop rollout with the gains of the preceding linearize_backward call."""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        xs_q = torch.empty(B, self.N + 1, 4, 4, **f64)
+        xs_xi = torch.empty(B, self.N + 1, 6, **f64)
+        us = torch.empty(B, self.N, self.m, **f64)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_rollout(self._h, int(ms), int(rollout == "linear"), float(alpha), B, _ptr(xs_q),
+                                       _ptr(xs_xi), _ptr(us), self._stream())
+        _capi.check(rc, "tolg_rollout")
+        return xs_q, xs_xi, us
+
+    # ------------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self.lib.tolg_enable_timing(self._h, int(on))
+
+    def kernel_time(self, reset=True):
+        """(ms in backward sweeps, ms in rollouts, ms in linearisation, number of backward launches)
+        measured with HIP events on the launch stream."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        self.lib.tolg_kernel_time(self._h, int(reset), C.byref(a), C.byref(b), C.byref(c), C.byref(n))
+        return a.value, b.value, c.value, n.value

@@ -1,0 +1,102 @@
+"""Synthetic workloads of the BASELINE.json configurations.
+
+The reference paths (q_ref, xi_ref, dt) are the reference's own data files re-saved as .npz under
+``data/`` (tests/golden/make_golden.py); everything else -- weights, nominal initial state, the
+seeded perturbation of the batch -- follows the reference's benchmark scripts:
+benchmark_SE3_tracking.py:67-79,175-190 and benchmark_drone_racing_tracking.py:56-66,168-210.
+Pure NumPy host code (no solver arithmetic here).
+"""
+import os
+
+import numpy as np
+
+from .solver import TrackingProblem
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+SEED = 24234156  # the reference's seed constant (main_SE3ddp_tracking_exact.py:22)
+
+
+def _skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    W = _skew(w)
+    if th < 1e-8:
+        return np.eye(3) + W + 0.5 * W @ W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+
+
+def _se3_exp(tau):
+    w, v = tau[:3], tau[3:]
+    th = np.linalg.norm(w)
+    W = _skew(w)
+    if th < 1e-8:
+        V = np.eye(3) + 0.5 * W
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * W + (th - np.sin(th)) / th ** 3 * W @ W
+    T = np.eye(4)
+    T[:3, :3] = _so3_exp(w)
+    T[:3, 3] = V @ v
+    return T
+
+
+def _rot_zxy(z, x, y):
+    """scipy Rotation.from_euler('zxy', [z, x, y], degrees=True).as_matrix(): lower-case axes are
+    extrinsic rotations about the fixed z, then x, then y axes."""
+    z, x, y = np.deg2rad([z, x, y])
+    Rz = np.array([[np.cos(z), -np.sin(z), 0], [np.sin(z), np.cos(z), 0], [0, 0, 1.0]])
+    Rx = np.array([[1.0, 0, 0], [0, np.cos(x), -np.sin(x)], [0, np.sin(x), np.cos(x)]])
+    Ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1.0, 0], [-np.sin(y), 0, np.cos(y)]])
+    return Ry @ Rx @ Rz
+
+
+def load_reference(name):
+    d = np.load(os.path.join(_DATA, "ref_%s.npz" % name))
+    return d["q_ref"], d["xi_ref"], float(d["dt"])
+
+
+def inertia():
+    return np.diag([0.5, 0.7, 0.9, 1.0, 1.0, 1.0])
+
+
+def perturbed_batch(q0, xi0, B, scale_pose, scale_twist, seed=SEED):
+    """q0_b = q0 Exp(delta_b), xi0_b = xi0 + eta_b."""
+    rng = np.random.default_rng(seed)
+    x0_q = np.empty((B, 4, 4))
+    x0_xi = np.empty((B, 6))
+    for b in range(B):
+        delta = rng.uniform(-1, 1, 6) * scale_pose
+        eta = rng.uniform(-1, 1, 6) * scale_twist
+        x0_q[b] = q0 @ _se3_exp(delta) if b > 0 else q0  # member 0 is the nominal problem
+        x0_xi[b] = xi0 + (eta if b > 0 else 0)
+    return x0_q, x0_xi
+
+
+def se3_tracking(B, N=200, R_scale=1e-5, seed=SEED):
+    """BASELINE metric / config 3: SE3 exact tracking, N=200, dt=0.05 on path_se3_generate_sine_2."""
+    q_ref, xi_ref, dt = load_reference("se3_sine2_n200")
+    q_ref, xi_ref = q_ref[: N + 1], xi_ref[: N + 1]
+    Q = np.diag([25.0, 25, 25, 10, 10, 10, 1, 1, 1, 1, 1, 1])
+    prob = TrackingProblem("se3", inertia(), dt, Q, np.eye(6) * R_scale, 1.5 * Q, q_ref, xi_ref)
+    q0 = np.eye(4)
+    q0[:3, :3] = _rot_zxy(90.0, 10.0, 45.0)
+    q0[:3, 3] = q_ref[0][:3, 3] - 1.0
+    xi0 = np.ones(6) * 0.1
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), 0.1, seed)
+    return prob, x0_q, x0_xi, np.zeros((B, N, 6))
+
+
+def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED):
+    """Config 5: DroneDynamics on the first N+1 knots of path_dense_random_columns_4obj (dt=0.004)."""
+    q_ref, xi_ref, dt = load_reference("drone_columns_n400")
+    q_ref, xi_ref = q_ref[: N + 1], xi_ref[: N + 1]
+    Q = np.diag([25.0, 25, 25, 10, 10, 10, 1, 1, 1, 1, 1, 1])
+    prob = TrackingProblem("drone", inertia(), dt, Q, np.eye(4) * R_scale, 1.5 * Q, q_ref, xi_ref)
+    q0 = np.eye(4)
+    q0[:3, :3] = _rot_zxy(1e-4, 0.0, 0.0)
+    q0[:3, 3] = q_ref[0][:3, 3] - 0.1
+    xi0 = np.ones(6) * 1e-3
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, 0.1 * np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), 0.01, seed)
+    return prob, x0_q, x0_xi, np.zeros((B, N, 4))
