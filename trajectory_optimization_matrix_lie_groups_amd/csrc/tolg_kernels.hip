@@ -32,10 +32,16 @@ struct Consts {
   int kind, m, N, pad;
   double dt, mass, grav, pad2;
   double J[36], Jinv[36], Ib[9];
+  // J = blkdiag(Ib, Jv) (checked in tolg_create): the 3x3 blocks and their inverses
+  double Jv[9], Ibinv[9], Jvinv[9];
   double W1[36], W2[36], P1[36], P2[36];  // Q / P diagonal 6x6 blocks
   double R[36];                           // m x m
-  double Bc[36];                          // 6 x m: J^-1 Pu dt (non-zero block of F_u)
-  double Pu[36];                          // 6 x m
+  // F_u = [0; B2] dt with B2 = J^-1 Pu = blkdiag(Bt (3x3), Bb (3 x (m-3))), already times dt:
+  // Bt = Ib^-1 dt; Bb = Jv^-1 dt (m = 6) or its third column (drone: u3 is the body-z force)
+  double Bt[9], Bb[9];
+  // gravity block of F_x is linear in rte = R^T (0,0,-1): A21 = sum_a rte_a Llin[a] (times dt, 6x6
+  // row-major each, no m*g: App. C-Q2)
+  double Llin[3][36];
 };
 
 struct Params {
@@ -46,11 +52,10 @@ struct Params {
   double* cand;
   double* cand_u;
   const double* ref;   // [N+1][13] reference pose (quat, pos) and twist, batch-shared
-  double* SA;          // [N][12][Bp][13]   F_x (cols 0..11) | defect d (col 12)
-  double* SL;          // [N+1][6][Bp][8]   l_xx11 (cols 0..5) | l_x[0:6] (col 6) | l_x[6:12] (col 7)
+  double* REC;         // [N+1][REC_F][Bp] compact knot records written by K1 (fields: REC_*)
   double* SC;          // [N+1][Bp] stage costs
   double* SD;          // [N][Bp]   squared defects
-  double* GK;          // [N][m][Bp][13]    K (cols 0..11) | k (col 12)
+  double* GK;          // [N][m*13][Bp]     K (cols 0..11) | k (col 12), row-major per knot
   double *mu, *delta, *Jc, *dn, *grad;
   int *active, *iters, *status, *conv;
   double *J_hist, *grad_hist, *defect_hist, *alpha_hist, *mu_hist;
@@ -58,16 +63,64 @@ struct Params {
   double tol_grad, tol_defect, max_reg;
 };
 
-#define SIDX(c, i, b) ((((size_t)(c)) * (size_t)(P.N + 1) + (size_t)(i)) * (size_t)P.Bp + (size_t)(b))
-#define UIDX(c, i, b) ((((size_t)(c)) * (size_t)P.N + (size_t)(i)) * (size_t)P.Bp + (size_t)(b))
-#define SAIDX(i, r, b, j) (((((size_t)(i)) * 12 + (size_t)(r)) * (size_t)P.Bp + (size_t)(b)) * 13 + (size_t)(j))
-#define SLIDX(i, r, b, j) (((((size_t)(i)) * 6 + (size_t)(r)) * (size_t)P.Bp + (size_t)(b)) * 8 + (size_t)(j))
-#define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * (size_t)P.Bp + (size_t)(b)) * 13 + (size_t)(j))
+// every array is knot-major [knot][field][Bp]: one knot of one field is a contiguous run over the batch
+#define SIDX(c, i, b) ((((size_t)(i)) * 13 + (size_t)(c)) * (size_t)P.Bp + (size_t)(b))
+#define UIDX(c, i, b) ((((size_t)(i)) * (size_t)P.m + (size_t)(c)) * (size_t)P.Bp + (size_t)(b))
+
+// Raw buffer access for the sequential kernels: the descriptor (SRD) addresses one knot, the lane
+// supplies a 32-bit byte offset (its trajectory), the field offset is a wave-uniform SGPR -- no
+// 64-bit per-lane address arithmetic in the sweep loops, and out-of-range reads return 0.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+TOLG_DEV __amdgpu_buffer_rsrc_t mkbuf(const double* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, bytes, 0x00020000);
+}
+TOLG_DEV double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+TOLG_DEV void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
+}
+// Knot record: everything K2/K3 need from the linearisation, one field per [Bp]-long row so that K1
+// (thread per trajectory, batch fastest) writes fully coalesced and K2's lanes pick the entries of
+// their own column by address.  3x3 blocks are stored column-major (column c at +3c).
+enum {
+  REC_RI = 0,    // R(Exp(xi dt))^T                     -> F_x[0:3,0:3] = F_x[3:6,3:6]
+  REC_TRI = 9,   // [t_inv]x R^T                        -> F_x[3:6,0:3]
+  REC_JR = 18,   // dt Jr(w dt)                         -> F_x[0:3,6:9] = F_x[3:6,9:12]
+  REC_QR = 27,   // dt Q(-v dt,-w dt)                   -> F_x[3:6,6:9]
+  REC_D = 36,    // defect (12)
+  REC_RTE = 48,  // R^T (0,0,-1) (gravity direction in the body frame), 0 for SE3Dynamics
+  REC_LXX = 51,  // l_xx pose block, symmetric packed (21)
+  REC_LX = 72,   // l_x (12)
+  REC_M = 84,    // rollout left factor M = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 (quaternion xyzw, t)
+  REC_C = 91,    // rollout offset c = xi_{i+1} - f_xi(x_i,u_i) + d_xi
+  REC_A22 = 97,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
+  REC_F = 133
+};
+#define RIDX(i, f, b) ((((size_t)(i)) * REC_F + (size_t)(f)) * (size_t)P.Bp + (size_t)(b))
+#define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * 13 + (size_t)(j)) * (size_t)P.Bp + (size_t)(b))
+__host__ __device__ inline int sym6(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
 
 // ------------------------------------------------------------------------------------------------
 // shared per-thread dynamics pieces
 // ------------------------------------------------------------------------------------------------
 struct State { Pose X; V3 w, v; };
+
+// one knot of a state array through its descriptor: 13 fields, sB bytes apart
+TOLG_DEV State load_state_b(__amdgpu_buffer_rsrc_t r, unsigned vb, unsigned sB) {
+  State S;
+  S.X.q.x = bld(r, vb, 0); S.X.q.y = bld(r, vb, sB); S.X.q.z = bld(r, vb, 2 * sB); S.X.q.w = bld(r, vb, 3 * sB);
+  S.X.t = v3(bld(r, vb, 4 * sB), bld(r, vb, 5 * sB), bld(r, vb, 6 * sB));
+  S.w = v3(bld(r, vb, 7 * sB), bld(r, vb, 8 * sB), bld(r, vb, 9 * sB));
+  S.v = v3(bld(r, vb, 10 * sB), bld(r, vb, 11 * sB), bld(r, vb, 12 * sB));
+  return S;
+}
+TOLG_DEV void store_state_b(__amdgpu_buffer_rsrc_t r, unsigned vb, unsigned sB, const State& S) {
+  bst(r, vb, 0, S.X.q.x); bst(r, vb, sB, S.X.q.y); bst(r, vb, 2 * sB, S.X.q.z); bst(r, vb, 3 * sB, S.X.q.w);
+  bst(r, vb, 4 * sB, S.X.t.x); bst(r, vb, 5 * sB, S.X.t.y); bst(r, vb, 6 * sB, S.X.t.z);
+  bst(r, vb, 7 * sB, S.w.x); bst(r, vb, 8 * sB, S.w.y); bst(r, vb, 9 * sB, S.w.z);
+  bst(r, vb, 10 * sB, S.v.x); bst(r, vb, 11 * sB, S.v.y); bst(r, vb, 12 * sB, S.v.z);
+}
 
 TOLG_DEV State load_state(const Params& P, const double* __restrict__ s, int i, int b) {
   State S;
@@ -86,40 +139,33 @@ TOLG_DEV void store_state(const Params& P, double* __restrict__ s, int i, int b,
 
 // fd_euler (traopt_dynamics.py:763-787 SE3, :1373-1401 Drone, :1049-1077 RigidBody):
 // q+ = q Exp(xi dt) (re-normalised), xi+ = xi + J^-1 (ad(xi)^T J xi + g(q) + Pu u) dt
+TOLG_DEV V3 mv33(const double* A, V3 x) {
+  return v3(A[0] * x.x + A[1] * x.y + A[2] * x.z, A[3] * x.x + A[4] * x.y + A[5] * x.z,
+            A[6] * x.x + A[7] * x.y + A[8] * x.z);
+}
+// entry (6 + r, u) of F_u (m columns), r = 0..5
+template <int M>
+TOLG_DEV double fu_entry(const Consts& C, int r, int u) {
+  if (r < 3) return (u < 3) ? C.Bt[3 * r + u] : 0.0;
+  return (u >= 3) ? C.Bb[3 * (r - 3) + (u - 3)] : 0.0;
+}
 template <int M>
 TOLG_DEV State dyn_f(const Consts& C, const State& S, const double (&u)[M]) {
   State F;
-  double dt = C.dt;
+  const double dt = C.dt;
   Pose E = se3_exp(dt * S.w, dt * S.v);
   F.X = se3_project(se3_compose(S.X, E));
-  double xi[6] = {S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
-  double Jxi[6];
-#pragma unroll
-  for (int a = 0; a < 6; a++) {
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) s += C.J[6 * a + k] * xi[k];
-    Jxi[a] = s;
-  }
-  V3 y1 = v3(Jxi[0], Jxi[1], Jxi[2]), y2 = v3(Jxi[3], Jxi[4], Jxi[5]);
-  V3 top = cross(y1, S.w) + cross(y2, S.v);  // ad(xi)^T y, upper half
+  // J = blkdiag(Ib, Jv): J xi = [Ib w; Jv v]
+  V3 y1 = mv33(C.Ib, S.w), y2 = mv33(C.Jv, S.v);
+  V3 top = cross(y1, S.w) + cross(y2, S.v);  // ad(xi)^T (J xi), upper half
   V3 bot = cross(y2, S.w);
   if (C.grav != 0.0) bot = bot + (C.mass * C.grav) * qrot_inv(S.X.q, v3(0, 0, -1.0));
-  double rhs[6] = {top.x, top.y, top.z, bot.x, bot.y, bot.z};
-#pragma unroll
-  for (int a = 0; a < 6; a++)
-#pragma unroll
-    for (int k = 0; k < M; k++) rhs[a] += C.Pu[a * M + k] * u[k];
-  double xn[6];
-#pragma unroll
-  for (int a = 0; a < 6; a++) {
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) s += C.Jinv[6 * a + k] * rhs[k];
-    xn[a] = xi[a] + dt * s;
-  }
-  F.w = v3(xn[0], xn[1], xn[2]);
-  F.v = v3(xn[3], xn[4], xn[5]);
+  // Pu u: identity (SE3 / RigidBody) or the drone selector (u0..2 -> torque, u3 -> f_z)
+  top = top + v3(u[0], u[1], u[2]);
+  if constexpr (M == 6) bot = bot + v3(u[3], u[4], u[5]);
+  else bot = bot + v3(0, 0, u[3]);
+  F.w = S.w + dt * mv33(C.Ibinv, top);
+  F.v = S.v + dt * mv33(C.Jvinv, bot);
   return F;
 }
 
@@ -327,43 +373,34 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = 0;
+      for (int c = a; c < 6; c++) {  // upper triangle; l_xx = 2 Je^T W1 Je is symmetric for symmetric W1
+        double s = 0, s2 = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += Je[6 * k + a] * WJ[6 * k + c];
-        P.SL[SLIDX(i, a, b, c)] = 2 * s;
+        for (int k = 0; k < 6; k++) { s += Je[6 * k + a] * WJ[6 * k + c]; s2 += Je[6 * k + c] * WJ[6 * k + a]; }
+        P.REC[RIDX(i, REC_LXX + sym6(a, c), b)] = s + s2;  // == 2 * symmetric part
       }
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) s += Je[6 * k + a] * We[k];
-      P.SL[SLIDX(i, a, b, 6)] = 2 * s;
-      P.SL[SLIDX(i, a, b, 7)] = 2 * W2v[a];
+      P.REC[RIDX(i, REC_LX + a, b)] = 2 * s;
+      P.REC[RIDX(i, REC_LX + 6 + a, b)] = 2 * W2v[a];
     }
   }
   if (term) return;
-  // ---------------- dynamics Jacobian (traopt_dynamics.py:802-837, :1416-1469)
+  // ---------------- dynamics Jacobian blocks (traopt_dynamics.py:802-837, :1416-1469)
   V3 wd = dt * S.w, vd = dt * S.v;
   SO3Coef kc = so3_coef(dot(wd, wd), true);
   Pose E;
   E.q = so3_exp(wd);
   E.t = ljac_apply(wd, kc, vd);
   {
-    // A11 = Ad(Exp(tau))^-1 = Ad(E^-1) = [[Ri,0],[[ti]x Ri, Ri]]
+    // Ad(Exp(tau))^-1 = Ad(E^-1) = [[Ri,0],[[ti]x Ri, Ri]]
     Pose Ei = se3_inverse(E);
     double Ri[9], Ti[9], TR[9];
     q_to_R(Ei.q, Ri);
     skew(Ei.t, Ti);
     mul33(Ti, Ri, TR);
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        P.SA[SAIDX(i, a, b, c)] = Ri[3 * a + c];
-        P.SA[SAIDX(i, a, b, c + 3)] = 0;
-        P.SA[SAIDX(i, a + 3, b, c)] = TR[3 * a + c];
-        P.SA[SAIDX(i, a + 3, b, c + 3)] = Ri[3 * a + c];
-      }
-    // A12 = Jr(tau) dt = [[Jr3,0],[Qr,Jr3]] dt, Jr(tau) = Jl(-tau)
+    // Jr(tau) dt = [[Jr3,0],[Qr,Jr3]] dt, Jr(tau) = Jl(-tau)
     double Jr3[9], Qr[9];
     ljac33(neg(wd), kc, Jr3);
     Q33(neg(vd), neg(wd), kc, Qr);
@@ -371,98 +408,82 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     for (int a = 0; a < 3; a++)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        P.SA[SAIDX(i, a, b, c + 6)] = dt * Jr3[3 * a + c];
-        P.SA[SAIDX(i, a, b, c + 9)] = 0;
-        P.SA[SAIDX(i, a + 3, b, c + 6)] = dt * Qr[3 * a + c];
-        P.SA[SAIDX(i, a + 3, b, c + 9)] = dt * Jr3[3 * a + c];
+        P.REC[RIDX(i, REC_RI + 3 * c + a, b)] = Ri[3 * a + c];
+        P.REC[RIDX(i, REC_TRI + 3 * c + a, b)] = TR[3 * a + c];
+        P.REC[RIDX(i, REC_JR + 3 * c + a, b)] = dt * Jr3[3 * a + c];
+        P.REC[RIDX(i, REC_QR + 3 * c + a, b)] = dt * Qr[3 * a + c];
       }
   }
   {
-    // A22 = I + H dt, H = J^-1 (coadjoint([v, w]) J + G)   <- literal swapped twist (App. C-Q1)
-    double Mx[36];
-    double Sv[9], Sw[9], SIw[9];
+    // A22 = I + H dt, H = J^-1 (coadjoint([v, w]) J + G)  <- literal swapped twist (App. C-Q1)
+    // with J = blkdiag(Ib, Jv): coadjoint([v,w]) J + G = [[S(Ib w) - Sv Ib, m Sv - Sw Jv],[m Sv, -Sv Jv]]
+    double Sv[9], Sw[9], SIw[9], M11[9], M12[9], M21[9], M22[9], T1[9], T2[9];
     skew(S.v, Sv);
     skew(S.w, Sw);
-    V3 Ibw = v3(C.Ib[0] * S.w.x + C.Ib[1] * S.w.y + C.Ib[2] * S.w.z, C.Ib[3] * S.w.x + C.Ib[4] * S.w.y + C.Ib[5] * S.w.z,
-                C.Ib[6] * S.w.x + C.Ib[7] * S.w.y + C.Ib[8] * S.w.z);
-    skew(Ibw, SIw);
-    // coadjoint([v,w]) = [[-Sv, -Sw],[0, -Sv]]
-    double co[36];
+    skew(mv33(C.Ib, S.w), SIw);
+    mul33(Sv, C.Ib, T1);
+    mul33(Sw, C.Jv, T2);
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = C.mass * Sv[k] - T2[k]; M21[k] = C.mass * Sv[k]; }
+    mul33(Sv, C.Jv, T1);
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        co[6 * a + c] = -Sv[3 * a + c];
-        co[6 * a + c + 3] = -Sw[3 * a + c];
-        co[6 * (a + 3) + c] = 0;
-        co[6 * (a + 3) + c + 3] = -Sv[3 * a + c];
-      }
+    for (int k = 0; k < 9; k++) M22[k] = -T1[k];
+    double H11[9], H12[9], H21[9], H22[9];
+    mul33(C.Ibinv, M11, H11);
+    mul33(C.Ibinv, M12, H12);
+    mul33(C.Jvinv, M21, H21);
+    mul33(C.Jvinv, M22, H22);
 #pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) s += co[6 * a + k] * C.J[6 * k + c];
-        Mx[6 * a + c] = s;
-      }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        Mx[6 * a + c] += SIw[3 * a + c];
-        Mx[6 * a + c + 3] += C.mass * Sv[3 * a + c];
-        Mx[6 * (a + 3) + c] += C.mass * Sv[3 * a + c];
-      }
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) s += C.Jinv[6 * a + k] * Mx[6 * k + c];
-        P.SA[SAIDX(i, a + 6, b, c + 6)] = (a == c ? 1.0 : 0.0) + dt * s;
-      }
-    // A21 = J^-1 [[0,0],[skew(R^T e3-), 0]] dt   (no m*g: App. C-Q2); zero for SE3Dynamics
-    double Sg[9];
-    if (C.grav != 0.0) {
-      skew(qrot_inv(S.X.q, v3(0, 0, -1.0)), Sg);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; k++) Sg[k] = 0;
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) s += C.Jinv[6 * a + 3 + k] * Sg[3 * k + c];
-        P.SA[SAIDX(i, a + 6, b, c)] = dt * s;
-        P.SA[SAIDX(i, a + 6, b, c + 3)] = 0;
+        double id = (r == c) ? 1.0 : 0.0;
+        P.REC[RIDX(i, REC_A22 + 6 * c + r, b)] = id + dt * H11[3 * r + c];
+        P.REC[RIDX(i, REC_A22 + 6 * (c + 3) + r, b)] = dt * H12[3 * r + c];
+        P.REC[RIDX(i, REC_A22 + 6 * c + r + 3, b)] = dt * H21[3 * r + c];
+        P.REC[RIDX(i, REC_A22 + 6 * (c + 3) + r + 3, b)] = id + dt * H22[3 * r + c];
       }
   }
+  {
+    V3 rte = (C.grav != 0.0) ? qrot_inv(S.X.q, v3(0, 0, -1.0)) : v3(0, 0, 0);
+    P.REC[RIDX(i, REC_RTE + 0, b)] = rte.x;
+    P.REC[RIDX(i, REC_RTE + 1, b)] = rte.y;
+    P.REC[RIDX(i, REC_RTE + 2, b)] = rte.z;
+  }
   // ---------------- defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}]  (traopt_controller.py:2882-2888)
+  // and the rollout factors of traopt_controller.py:2713-2716 for alpha = 1
   double d[12];
+  Pose Mx;
+  V3 cw, cv;
   if (ms) {
     State F = dyn_f<M>(C, S, u);
     State Sn = load_state(P, src, i + 1, b);
     V3 dw, dv;
     se3_log(se3_compose(se3_inverse(Sn.X), F.X), dw, dv);
     d[0] = dw.x; d[1] = dw.y; d[2] = dw.z; d[3] = dv.x; d[4] = dv.y; d[5] = dv.z;
-    d[6] = F.w.x - Sn.w.x; d[7] = F.w.y - Sn.w.y; d[8] = F.w.z - Sn.w.z;
-    d[9] = F.v.x - Sn.v.x; d[10] = F.v.y - Sn.v.y; d[11] = F.v.z - Sn.v.z;
+    V3 dxw = F.w - Sn.w, dxv = F.v - Sn.v;
+    d[6] = dxw.x; d[7] = dxw.y; d[8] = dxw.z; d[9] = dxv.x; d[10] = dxv.y; d[11] = dxv.z;
+    Mx = se3_compose(se3_compose(Sn.X, se3_exp(dw, dv)), se3_inverse(F.X));
+    cw = Sn.w - F.w + dxw;
+    cv = Sn.v - F.v + dxv;
   } else {
 #pragma unroll
     for (int a = 0; a < 12; a++) d[a] = 0;
+    Mx.q.x = 0; Mx.q.y = 0; Mx.q.z = 0; Mx.q.w = 1; Mx.t = v3(0, 0, 0);
+    cw = v3(0, 0, 0); cv = v3(0, 0, 0);
   }
   double d2 = 0;
 #pragma unroll
   for (int a = 0; a < 12; a++) {
-    P.SA[SAIDX(i, a, b, 12)] = d[a];
+    P.REC[RIDX(i, REC_D + a, b)] = d[a];
     d2 += d[a] * d[a];
   }
   P.SD[(size_t)i * P.Bp + b] = d2;
+  P.REC[RIDX(i, REC_M + 0, b)] = Mx.q.x; P.REC[RIDX(i, REC_M + 1, b)] = Mx.q.y;
+  P.REC[RIDX(i, REC_M + 2, b)] = Mx.q.z; P.REC[RIDX(i, REC_M + 3, b)] = Mx.q.w;
+  P.REC[RIDX(i, REC_M + 4, b)] = Mx.t.x; P.REC[RIDX(i, REC_M + 5, b)] = Mx.t.y; P.REC[RIDX(i, REC_M + 6, b)] = Mx.t.z;
+  P.REC[RIDX(i, REC_C + 0, b)] = cw.x; P.REC[RIDX(i, REC_C + 1, b)] = cw.y; P.REC[RIDX(i, REC_C + 2, b)] = cw.z;
+  P.REC[RIDX(i, REC_C + 3, b)] = cv.x; P.REC[RIDX(i, REC_C + 4, b)] = cv.y; P.REC[RIDX(i, REC_C + 5, b)] = cv.z;
 }
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
@@ -470,9 +491,18 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 __global__ void k_reduce(Params P, int it) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
+  // fixed summation order (knot 0, 1, 2, ...) with the loads batched eight at a time
   double J = 0, d2 = 0;
-  for (int i = 0; i <= P.N; i++) J += P.SC[(size_t)i * P.Bp + b];
-  for (int i = 0; i < P.N; i++) d2 += P.SD[(size_t)i * P.Bp + b];
+  int i = 0;
+  for (; i + 8 <= P.N; i += 8) {
+    double c[8], d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c[k] = P.SC[(size_t)(i + k) * P.Bp + b]; d[k] = P.SD[(size_t)(i + k) * P.Bp + b]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { J += c[k]; d2 += d[k]; }
+  }
+  for (; i < P.N; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
+  J += P.SC[(size_t)P.N * P.Bp + b];
   double dn = sqrt(d2);
   P.Jc[b] = J;
   P.dn[b] = dn;
@@ -504,6 +534,28 @@ TOLG_DEV void rank1_bi(double (&acc)[12], double p, double q) {
                            FM("%9", "%12", "%13", 9) FM("%10", "%12", "%13", 10) FM("%11", "%12", "%13", 11)
                : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
                  "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
+               : "v"(p), "v"(q));
+}
+// same, restricted to the 3-row blocks of P^T that are structurally non-zero (F_x block pattern)
+#define FM3(a0, a1, a2, p, q, L0, L1, L2) FM(a0, p, q, L0) FM(a1, p, q, L1) FM(a2, p, q, L2)
+// rows {0,1,2, 6,7,8}: used for k in the first row block of F_x = [Ri 0 Jr 0]
+TOLG_DEV void rank1_bi_02(double (&acc)[12], double p, double q) {
+  asm volatile("s_nop 1\n\t" FM3("%0", "%1", "%2", "%6", "%7", 0, 1, 2) FM3("%3", "%4", "%5", "%6", "%7", 6, 7, 8)
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8])
+               : "v"(p), "v"(q));
+}
+// rows {6..11}: k in the lower row blocks [0 0 A22] (SE3Dynamics)
+TOLG_DEV void rank1_bi_23(double (&acc)[12], double p, double q) {
+  asm volatile("s_nop 1\n\t" FM3("%0", "%1", "%2", "%6", "%7", 6, 7, 8) FM3("%3", "%4", "%5", "%6", "%7", 9, 10, 11)
+               : "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
+               : "v"(p), "v"(q));
+}
+// rows {0,1,2, 6..11}: lower row blocks with the gravity block [A21 0 A22] (Drone / RigidBody)
+TOLG_DEV void rank1_bi_023(double (&acc)[12], double p, double q) {
+  asm volatile("s_nop 1\n\t" FM3("%0", "%1", "%2", "%9", "%10", 0, 1, 2) FM3("%3", "%4", "%5", "%9", "%10", 6, 7, 8)
+                   FM3("%6", "%7", "%8", "%9", "%10", 9, 10, 11)
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]),
+                 "+v"(acc[10]), "+v"(acc[11])
                : "v"(p), "v"(q));
 }
 #define FMK(a, p, K) "v_fmac_f64_dpp " a ", " p ", %24 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
@@ -548,14 +600,29 @@ TOLG_DEV void rank1_bk(double (&acc)[12], const double (&Pm)[12], double q) {
 #pragma unroll
   for (int i = 0; i < 12; i++) acc[i] += bcast<K>(Pm[i]) * q;
 }
+TOLG_DEV void rank1_bi_02(double (&acc)[12], double p, double q) {
+  acc[0] += bcast<0>(p) * q; acc[1] += bcast<1>(p) * q; acc[2] += bcast<2>(p) * q;
+  acc[6] += bcast<6>(p) * q; acc[7] += bcast<7>(p) * q; acc[8] += bcast<8>(p) * q;
+}
+TOLG_DEV void rank1_bi_23(double (&acc)[12], double p, double q) {
+  acc[6] += bcast<6>(p) * q; acc[7] += bcast<7>(p) * q; acc[8] += bcast<8>(p) * q;
+  acc[9] += bcast<9>(p) * q; acc[10] += bcast<10>(p) * q; acc[11] += bcast<11>(p) * q;
+}
+TOLG_DEV void rank1_bi_023(double (&acc)[12], double p, double q) {
+  acc[0] += bcast<0>(p) * q; acc[1] += bcast<1>(p) * q; acc[2] += bcast<2>(p) * q;
+  rank1_bi_23(acc, p, q);
+}
 #endif
 
+// Cholesky of the symmetric part of Q (in place: on return the lower triangle of Q holds L with the
+// diagonal replaced by its reciprocal-free value, dinv the reciprocals).  Only the lower triangle
+// and diagonal of Q are read; the strict upper triangle keeps the original entries for lu_solve.
 template <int M>
-TOLG_DEV bool chol(const double (&S)[M][M], double (&L)[M][M], double (&dinv)[M]) {
+TOLG_DEV bool chol_sym(double (&L)[M][M], const double (&Q)[M][M], double (&dinv)[M]) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < M; j++) {
-    double d = S[j][j];
+    double d = Q[j][j];
 #pragma unroll
     for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
     ok = ok && (d > 0.0);
@@ -564,7 +631,7 @@ TOLG_DEV bool chol(const double (&S)[M][M], double (&L)[M][M], double (&dinv)[M]
     L[j][j] = dj;
 #pragma unroll
     for (int i = j + 1; i < M; i++) {
-      double s = S[i][j];
+      double s = 0.5 * (Q[i][j] + Q[j][i]);
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
       L[i][j] = s * dinv[j];
@@ -639,64 +706,109 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // lane-dependent constants
   const double m12 = (j < 12) ? 1.0 : 0.0;                  // matrix columns
   const double mvec = (j == 12 || j == 13) ? 1.0 : 0.0;     // vector columns (V_x, SS adjoint)
-  const double mA = (j < 13) ? 1.0 : 0.0;
+  const bool grav = C.grav != 0.0;
   double W2col[6], Rcol[M], Bloc[6], Brow[M];
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     W2col[r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
-    Bloc[r] = (j < M) ? C.Bc[r * M + j] : 0.0;               // B[6+r][j]
+    Bloc[r] = (j < M) ? fu_entry<M>(C, r, j) : 0.0;          // B[6+r][j]
   }
 #pragma unroll
   for (int u = 0; u < M; u++) {
     Rcol[u] = (j < M) ? 2.0 * C.R[u * M + j] : 0.0;
-    Brow[u] = (j >= 6 && j < 12) ? C.Bc[(j - 6) * M + u] : 0.0;  // B[j][u]
+    Brow[u] = (j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u) : 0.0;  // B[j][u]
   }
+  // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
+  int fT = REC_D, fM = REC_D + 3;
+  double mT = 0.0, mM = 0.0;
+  if (j < 3) { fT = REC_RI + 3 * j; fM = REC_TRI + 3 * j; mT = 1; mM = 1; }
+  else if (j < 6) { fM = REC_RI + 3 * (j - 3); mM = 1; }
+  else if (j < 9) { fT = REC_JR + 3 * (j - 6); fM = REC_QR + 3 * (j - 6); mT = 1; mM = 1; }
+  else if (j < 12) { fM = REC_JR + 3 * (j - 9); mM = 1; }
+  else if (j == 12) { mT = 1; mM = 1; }
+  int fL[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) fL[r] = (j < 6) ? REC_LXX + sym6(r, j) : REC_LX + r;
+  const double mLT = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
+  // rows 6..11 of column j: lanes 6..11 read their A22 column, lane 12 reads d[6:12], lanes 0..2
+  // (gravity models) build their A21 column from R^T e3 with per-lane constants
+  const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const unsigned vT = vb + (unsigned)fT * sB, vM = vb + (unsigned)fM * sB, vBt = vb + (unsigned)fB * sB;
+  const unsigned vG = vb + (unsigned)(j < 13 ? j : 12) * sB;
+  unsigned vL[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) vL[r] = vb + (unsigned)fL[r] * sB;
+  const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  const double mB = ((j >= 6 && j < 12) || j == 12) ? 1.0 : 0.0;
+  double Cg[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int r = 0; r < 6; r++) Cg[a][r] = (j < 3 && grav) ? C.Llin[a][6 * r + (j < 3 ? j : 0)] : 0.0;
   double mu = P.mu[b], delta = P.delta[b];
   int warned = 0;
 
   // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
   double V[12];
   {
-    const int c1 = (j < 6) ? j : 6;
-    const double mtop = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      double t1 = P.SL[SLIDX(N, r, b, c1)], t2 = P.SL[SLIDX(N, r, b, 7)];
-      V[r] = mtop * t1;
+      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, vb, (REC_LX + 6 + r) * sB);
+      V[r] = mLT * t1;
       double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
       V[6 + r] = mvec * t2 + p2;
     }
   }
   double gsum = 0;
 
-  for (int i = N - 1; i >= 0; i--) {
-    // ---- loads: column j of [F_x | d], of [l_xx | l_x], controls
-    double A[12], Lc[12];
-    {
-      const int jj = (j < 13) ? j : 12;
+  // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
+  // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
+  // data right behind the request and undo the prefetch.
+  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], uu[M]; };
+  auto load_knot = [&](int i, BwdIn& in) {
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB);
 #pragma unroll
-      for (int r = 0; r < 12; r++) A[r] = mA * P.SA[SAIDX(i, r, b, jj)];
-      const int c1 = (j < 6) ? j : 6;
-      const double mtop = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        double t1 = P.SL[SLIDX(i, r, b, c1)], t2 = P.SL[SLIDX(i, r, b, 7)];
-        Lc[r] = mtop * t1;
-        Lc[6 + r] = mvec * t2 + W2col[r];
-      }
+    for (int r = 0; r < 3; r++) {
+      in.t[r] = bld(rR, vT, r * sB);
+      in.m[r] = bld(rR, vM, r * sB);
     }
-    double lu[M];
-    {
-      double uu[M];
 #pragma unroll
-      for (int a = 0; a < M; a++) uu[a] = P.cur_u[UIDX(a, i, b)];
+    for (int r = 0; r < 6; r++) in.bt[r] = bld(rR, vBt, r * sB);
+    if (grav) {
 #pragma unroll
-      for (int a = 0; a < M; a++) {
-        double s = 0;
+      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, vb, (REC_RTE + a) * sB);
+    }
 #pragma unroll
-        for (int k = 0; k < M; k++) s += 2.0 * C.R[a * M + k] * uu[k];
-        lu[a] = mvec * s;  // l_u = 2 R u rides in the vector columns
-      }
+    for (int r = 0; r < 6; r++) {
+      in.lt[r] = bld(rR, vL[r], 0);
+      in.lb[r] = bld(rR, vb, (REC_LX + 6 + r) * sB);
+    }
+#pragma unroll
+    for (int a = 0; a < M; a++) in.uu[a] = bld(rU, vb, a * sB);
+  };
+
+  auto step = [&](int i, const BwdIn& in) {
+    __amdgpu_buffer_rsrc_t rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+    double A[12], Lc[12], lu[M];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { A[r] = mT * in.t[r]; A[3 + r] = mM * in.m[r]; }
+#pragma unroll
+    for (int r = 0; r < 6; r++) A[6 + r] = mB * in.bt[r];
+    if (grav) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) A[6 + r] += in.g[0] * Cg[0][r] + in.g[1] * Cg[1][r] + in.g[2] * Cg[2][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r] + W2col[r]; }
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      double sacc = 0;
+#pragma unroll
+      for (int k = 0; k < M; k++) sacc += 2.0 * C.R[a * M + k] * in.uu[k];
+      lu[a] = mvec * sacc;  // l_u = 2 R u rides in the vector columns
     }
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
@@ -711,8 +823,16 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     double Qh[12];
 #pragma unroll
     for (int r = 0; r < 12; r++) Qh[r] = Lc[r];
-#pragma unroll
-    for (int k = 0; k < 12; k++) rank1_bi(Qh, A[k], Z[k]);
+    // F_x = [Ri 0 Jr 0; TRi Ri Qr Jr; A21 0 A22 A22]: skip the structurally zero 3-row blocks
+    rank1_bi_02(Qh, A[0], Z[0]); rank1_bi_02(Qh, A[1], Z[1]); rank1_bi_02(Qh, A[2], Z[2]);
+    rank1_bi(Qh, A[3], Z[3]); rank1_bi(Qh, A[4], Z[4]); rank1_bi(Qh, A[5], Z[5]);
+    if (grav) {
+      rank1_bi_023(Qh, A[6], Z[6]); rank1_bi_023(Qh, A[7], Z[7]); rank1_bi_023(Qh, A[8], Z[8]);
+      rank1_bi_023(Qh, A[9], Z[9]); rank1_bi_023(Qh, A[10], Z[10]); rank1_bi_023(Qh, A[11], Z[11]);
+    } else {
+      rank1_bi_23(Qh, A[6], Z[6]); rank1_bi_23(Qh, A[7], Z[7]); rank1_bi_23(Qh, A[8], Z[8]);
+      rank1_bi_23(Qh, A[9], Z[9]); rank1_bi_23(Qh, A[10], Z[10]); rank1_bi_23(Qh, A[11], Z[11]);
+    }
 
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
     double Quh[M], Kh[M];
@@ -737,12 +857,14 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         // T = B^T (V + mu I), rows u, column per lane
         double T[M];
 #pragma unroll
-        for (int u = 0; u < M; u++) {
+        for (int u = 0; u < M; u++) {  // B2 is block diagonal: inputs 0..2 see rows 6..8, the rest rows 9..11
           double s = lu[u], tt = muA * Brow[u];
+          const int k0 = (u < 3) ? 0 : 3;
 #pragma unroll
-          for (int k = 0; k < 6; k++) {
-            s += C.Bc[k * M + u] * Xp[k];
-            tt += C.Bc[k * M + u] * V[6 + k];
+          for (int k = 0; k < 3; k++) {
+            const double bku = (u < 3) ? C.Bt[3 * k + u] : C.Bb[3 * k + (u - 3)];
+            s += bku * Xp[k0 + k];
+            tt += bku * V[6 + k0 + k];
           }
           Quh[u] = s;
           T[u] = m12 * tt;
@@ -767,12 +889,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
           if constexpr (M > 4) { Qrep[u][4] = bcast<4>(Quu[u]); Qrep[u][5] = bcast<5>(Quu[u]); }
         }
         // is_pos_def(Q_uu + Q_uu^T)  (traopt_utilis.py:320-329) on the symmetric part
-        double Ssym[M][M];
-#pragma unroll
-        for (int u = 0; u < M; u++)
-#pragma unroll
-          for (int k = 0; k < M; k++) Ssym[u][k] = 0.5 * (Qrep[u][k] + Qrep[k][u]);
-        bool pd = chol<M>(Ssym, Ls, dinv);
+        bool pd = chol_sym<M>(Ls, Qrep, dinv);
         if (!pd) {
           delta = fmax(1.0, delta) * 2.0;
           mu = fmax(1e-6, mu * delta);
@@ -815,7 +932,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
     if (act && j < 13) {
 #pragma unroll
-      for (int u = 0; u < M; u++) P.GK[GKIDX(i, u, b, j)] = Kh[u];
+      for (int u = 0; u < M; u++) bst(rG, vG, (unsigned)(u * 13) * sB, Kh[u]);
     }
     // ---- V <- Qh + Q_ux^T [K | k]   (== Eq. 11b/11c of traopt_controller.py:2998-3003 for the
     // exact gains), then symmetrise the matrix columns through LDS (traopt_controller.py:3004)
@@ -824,17 +941,30 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 12; r++) Vn[r] = Qh[r];
 #pragma unroll
     for (int u = 0; u < M; u++) rank1_bi(Vn, Quh[u], Kh[u]);
-    __syncthreads();
+    // One wavefront per workgroup: LDS operations of a wave execute in order, so the transpose
+    // needs no s_barrier -- and must not use __syncthreads(), whose vmcnt(0) would drain the
+    // prefetched loads and the gain stores twice per knot.  wave_barrier only pins the compiler.
+    __builtin_amdgcn_wave_barrier();
     if (j < 12) {
 #pragma unroll
       for (int r = 0; r < 12; r++) TR[g][r * 13 + j] = Vn[r];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 12; r++) {
       double vt = (j < 12) ? TR[g][j * 13 + r] : Vn[r];
       V[r] = 0.5 * (Vn[r] + vt);
     }
+  };
+
+  BwdIn Ia, Ib;
+  load_knot(N - 1, Ia);
+  for (int i = N - 1; i >= 0; i -= 2) {
+    if (i - 1 >= 0) load_knot(i - 1, Ib);
+    step(i, Ia);
+    if (i - 1 < 0) break;
+    if (i - 2 >= 0) load_knot(i - 2, Ia);
+    step(i - 1, Ib);
   }
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
   double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
@@ -855,86 +985,199 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: MS closed-loop rollout, one thread per trajectory (traopt_controller.py:2641-2740)
+// K3: closed-loop rollout, one thread per trajectory (traopt_controller.py:2641-2740 MS,
+// :2030-2082 SS).  The reference's MS step
+//     q^_{i+1} = q_{i+1} Exp(alpha d_q) f_q(x_i,u_i)^-1 f_q(x^_i,u^_i),
+//     xi^_{i+1} = xi_{i+1} + f_xi(x^_i,u^_i) - f_xi(x_i,u_i) + alpha d_xi
+// is M_i o f_q(x^_i,u^_i), c_i + f_xi(x^_i,u^_i) with (M_i, c_i) independent of the new trajectory:
+// K1 precomputes them in parallel for alpha = 1 (REC_M, REC_C; identity / zero for SS), so the
+// sequential chain holds one Log, one Exp and the K dx product per knot.
 // ------------------------------------------------------------------------------------------------
 template <int M>
-__global__ __launch_bounds__(64) void k_rollout_ms(Params P, double alpha, int linear) {
+TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const double (&e)[12],
+                       const double (&du)[M], double (&lin)[12]) {
+  // lin = F_x e + F_u du from the compact record (rollout == 'linear')
+  double Ri[9], TRi[9], Jr[9], Qr[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    Ri[k] = P.REC[RIDX(i, REC_RI + k, b)]; TRi[k] = P.REC[RIDX(i, REC_TRI + k, b)];
+    Jr[k] = P.REC[RIDX(i, REC_JR + k, b)]; Qr[k] = P.REC[RIDX(i, REC_QR + k, b)];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {  // blocks are column-major: X[r][c] = X_[3c + r]
+    double t = 0, m = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      t += Ri[3 * c + r] * e[c] + Jr[3 * c + r] * e[6 + c];
+      m += TRi[3 * c + r] * e[c] + Ri[3 * c + r] * e[3 + c] + Qr[3 * c + r] * e[6 + c] + Jr[3 * c + r] * e[9 + c];
+    }
+    lin[r] = t;
+    lin[3 + r] = m;
+  }
+  double rte[3] = {P.REC[RIDX(i, REC_RTE, b)], P.REC[RIDX(i, REC_RTE + 1, b)], P.REC[RIDX(i, REC_RTE + 2, b)]};
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    double sacc = e[6 + r];
+#pragma unroll
+    for (int c = 0; c < 6; c++) sacc += (P.REC[RIDX(i, REC_A22 + 6 * c + r, b)] - (r == c ? 1.0 : 0.0)) * e[6 + c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double l = rte[0] * C.Llin[0][6 * r + c] + rte[1] * C.Llin[1][6 * r + c] + rte[2] * C.Llin[2][6 * r + c];
+      sacc += l * e[c];
+    }
+#pragma unroll
+    for (int k = 0; k < M; k++) sacc += fu_entry<M>(C, r, k) * du[k];
+    lin[6 + r] = sacc;
+  }
+}
+
+// What one rollout step reads.  The nominal state (needed first, by Log) is fetched one knot ahead
+// (ping-pong registers); gains, controls and the rollout factors are requested at the top of the
+// step and arrive while Log runs.  64 waves cannot hide memory latency any other way.
+template <int M>
+struct RollIn {
+  double G[M * 13];  // gains [K | k], row-major
+  double u[M];
+  Pose Mx;           // REC_M
+  V3 cw, cv;         // REC_C
+};
+TOLG_DEV State roll_load_state(const Params& P, int i, unsigned vb, unsigned sB) {
+  return load_state_b(mkbuf(P.cur + (size_t)13 * P.Bp * i, 13 * sB), vb, sB);
+}
+template <int M, bool ALPHA1>
+TOLG_DEV void roll_load(const Params& P, int i, unsigned vb, unsigned sB, RollIn<M>& R) {
+  const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+  __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+#pragma unroll
+  for (int k = 0; k < M * 13; k++) R.G[k] = bld(rG, vb, (unsigned)k * sB);
+#pragma unroll
+  for (int a = 0; a < M; a++) R.u[a] = bld(rU, vb, a * sB);
+  if constexpr (ALPHA1) {
+    R.Mx.q.x = bld(rR, vb, (REC_M + 0) * sB); R.Mx.q.y = bld(rR, vb, (REC_M + 1) * sB);
+    R.Mx.q.z = bld(rR, vb, (REC_M + 2) * sB); R.Mx.q.w = bld(rR, vb, (REC_M + 3) * sB);
+    R.Mx.t = v3(bld(rR, vb, (REC_M + 4) * sB), bld(rR, vb, (REC_M + 5) * sB), bld(rR, vb, (REC_M + 6) * sB));
+    R.cw = v3(bld(rR, vb, (REC_C + 0) * sB), bld(rR, vb, (REC_C + 1) * sB), bld(rR, vb, (REC_C + 2) * sB));
+    R.cv = v3(bld(rR, vb, (REC_C + 3) * sB), bld(rR, vb, (REC_C + 4) * sB), bld(rR, vb, (REC_C + 5) * sB));
+  }
+}
+
+template <int M, bool LINEAR, bool ALPHA1>
+TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigned vb, unsigned sB, double alpha,
+                         const State& So, const State& Sn) {
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
+  RollIn<M> R;
+  roll_load<M, ALPHA1>(P, i, vb, sB, R);  // in flight while Log runs
+  // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
+  V3 ew, ev;
+  se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+  double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                  Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+  double un[M], du[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) {
+    double s = alpha * R.G[a * 13 + 12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s += R.G[a * 13 + k] * e[k];
+    du[a] = s;
+    un[a] = R.u[a] + s;
+  }
+  State Nx;
+  if constexpr (!LINEAR) {
+    State Fn = dyn_f<M>(C, Sn, un);
+    Pose Mx;
+    V3 cw, cv;
+    if constexpr (ALPHA1) {
+      Mx = R.Mx; cw = R.cw; cv = R.cv;
+    } else {
+      // line-search step: rebuild the factors for this alpha from the stored defect
+      __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+      double d[12];
+#pragma unroll
+      for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, R.u);
+      Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
+                       se3_inverse(Fo.X));
+      cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
+      cv = Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
+    }
+    Nx.X = se3_project(se3_compose(Mx, Fn.X));
+    Nx.w = cw + Fn.w;
+    Nx.v = cv + Fn.v;
+  } else {
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    double lin[12], d[12];
+    fx_apply<M>(P, C, i, b, e, du, lin);
+#pragma unroll
+    for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, vb, (REC_D + a) * sB);
+    State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+    Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
+    Nx.X = se3_project(se3_compose(Sx.X, D));
+    Nx.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
+    Nx.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
+  }
+  __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
+#pragma unroll
+  for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
+  store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+  return Nx;
+}
+
+template <int M, bool LINEAR, bool ALPHA1>
+__global__ __launch_bounds__(64) void k_rollout(Params P, double alpha) {
   const Consts& C = *P.c;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
   const int N = P.N;
-  State Sn = load_state(P, P.cur, 0, b);  // new trajectory, knot i
-  State So = Sn;                          // nominal, knot i
-  store_state(P, P.cand, 0, b, Sn);
-  for (int i = 0; i < N; i++) {
-    State Sx = load_state(P, P.cur, i + 1, b);  // nominal knot i+1
-    // state deviation [Log(q^-1 q_new); xi_new - xi]
-    V3 ew, ev;
-    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
-    double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
-                    Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
-    double u[M], un[M], du[M];
-#pragma unroll
-    for (int a = 0; a < M; a++) {
-      double s = alpha * P.GK[GKIDX(i, a, b, 12)];
-#pragma unroll
-      for (int k = 0; k < 12; k++) s += P.GK[GKIDX(i, a, b, k)] * e[k];
-      u[a] = P.cur_u[UIDX(a, i, b)];
-      du[a] = s;
-      un[a] = u[a] + s;
-      P.cand_u[UIDX(a, i, b)] = un[a];
-    }
-    double d[12];
-#pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = P.SA[SAIDX(i, a, b, 12)];
-    State Nx;
-    if (!linear) {
-      State Fn = dyn_f<M>(C, Sn, un), Fo = dyn_f<M>(C, So, u);
-      Pose D = se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]));
-      Nx.X = se3_project(se3_compose(se3_compose(se3_compose(Sx.X, D), se3_inverse(Fo.X)), Fn.X));
-      Nx.w = Sx.w + Fn.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
-      Nx.v = Sx.v + Fn.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
-    } else {
-      double lin[12];
-#pragma unroll
-      for (int a = 0; a < 12; a++) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) s += P.SA[SAIDX(i, a, b, k)] * e[k];
-        if (a >= 6) {
-#pragma unroll
-          for (int k = 0; k < M; k++) s += C.Bc[(a - 6) * M + k] * du[k];
-        }
-        lin[a] = s;
-      }
-      Pose D = se3_exp(v3(lin[0] + alpha * d[0], lin[1] + alpha * d[1], lin[2] + alpha * d[2]),
-                       v3(lin[3] + alpha * d[3], lin[4] + alpha * d[4], lin[5] + alpha * d[5]));
-      Nx.X = se3_project(se3_compose(Sx.X, D));
-      Nx.w = Sx.w + v3(lin[6] + alpha * d[6], lin[7] + alpha * d[7], lin[8] + alpha * d[8]);
-      Nx.v = Sx.v + v3(lin[9] + alpha * d[9], lin[10] + alpha * d[10], lin[11] + alpha * d[11]);
-    }
-    store_state(P, P.cand, i + 1, b, Nx);
-    Sn = Nx;
-    So = Sx;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);  // new trajectory, knot i
+  store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
+  State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+  for (int i = 0; i < N; i += 2) {
+    if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
+    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i, b, vb, sB, alpha, Sa, Sn);
+    if (i + 1 >= N) break;
+    if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
+    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i + 1, b, vb, sB, alpha, Sb, Sn);
   }
 }
 
 // export kernels for the unit-parity entry point
 __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restrict__ d, double* __restrict__ lx,
                              double* __restrict__ lxx11, double* __restrict__ kk, double* __restrict__ K) {
+  const Consts& C = *P.c;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)(P.N + 1) * P.B) return;
   int b = (int)(t % P.B), i = (int)(t / P.B);
   size_t bi = (size_t)b * (P.N + 1) + i, bn = (size_t)b * P.N + i;
   for (int r = 0; r < 6; r++) {
-    if (lxx11) for (int c = 0; c < 6; c++) lxx11[(bi * 6 + r) * 6 + c] = P.SL[SLIDX(i, r, b, c)];
-    if (lx) { lx[bi * 12 + r] = P.SL[SLIDX(i, r, b, 6)]; lx[bi * 12 + 6 + r] = P.SL[SLIDX(i, r, b, 7)]; }
+    if (lxx11) for (int c = 0; c < 6; c++) lxx11[(bi * 6 + r) * 6 + c] = P.REC[RIDX(i, REC_LXX + sym6(r, c), b)];
+    if (lx) { lx[bi * 12 + r] = P.REC[RIDX(i, REC_LX + r, b)]; lx[bi * 12 + 6 + r] = P.REC[RIDX(i, REC_LX + 6 + r, b)]; }
   }
   if (i == P.N) return;
-  for (int r = 0; r < 12; r++) {
-    if (Fx) for (int c = 0; c < 12; c++) Fx[(bn * 12 + r) * 12 + c] = P.SA[SAIDX(i, r, b, c)];
-    if (d) d[bn * 12 + r] = P.SA[SAIDX(i, r, b, 12)];
+  if (Fx) {  // re-assemble the dense 12x12 the reference returns from the compact record
+    double* F = Fx + bn * 144;
+    for (int k = 0; k < 144; k++) F[k] = 0;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double ri = P.REC[RIDX(i, REC_RI + 3 * c + r, b)], jr = P.REC[RIDX(i, REC_JR + 3 * c + r, b)];
+        F[12 * r + c] = ri; F[12 * (r + 3) + c + 3] = ri;
+        F[12 * (r + 3) + c] = P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
+        F[12 * r + c + 6] = jr; F[12 * (r + 3) + c + 9] = jr;
+        F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
+      }
+    double rte[3];
+    for (int a = 0; a < 3; a++) rte[a] = P.REC[RIDX(i, REC_RTE + a, b)];
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        double l = 0;
+        for (int a = 0; a < 3; a++) l += rte[a] * C.Llin[a][6 * r + c];
+        F[12 * (r + 6) + c + 6] = P.REC[RIDX(i, REC_A22 + 6 * c + r, b)];
+        F[12 * (r + 6) + c] = l;
+      }
   }
+  for (int r = 0; r < 12; r++)
+    if (d) d[bn * 12 + r] = P.REC[RIDX(i, REC_D + r, b)];
   for (int u = 0; u < P.m; u++) {
     if (K) for (int c = 0; c < 12; c++) K[(bn * P.m + u) * 12 + c] = P.GK[GKIDX(i, u, b, c)];
     if (kk) kk[bn * P.m + u] = P.GK[GKIDX(i, u, b, 12)];
@@ -1019,8 +1262,7 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   double* cur_u = c.take<double>(m * N * B);
   double* cand = c.take<double>(13 * (N + 1) * B);
   double* cand_u = c.take<double>(m * N * B);
-  double* SA = c.take<double>(N * 12 * B * 13);
-  double* SL = c.take<double>((N + 1) * 6 * B * 8);
+  double* REC = c.take<double>((N + 1) * (size_t)REC_F * B);
   double* SC = c.take<double>((N + 1) * B);
   double* SD = c.take<double>(N * B);
   double* GK = c.take<double>(N * m * B * 13);
@@ -1035,7 +1277,7 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* conv = c.take<int>(B);
   if (P) {
     P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
-    P->SA = SA; P->SL = SL; P->SC = SC; P->SD = SD; P->GK = GK; P->mu = mu; P->delta = delta; P->Jc = Jc;
+    P->REC = REC; P->SC = SC; P->SD = SD; P->GK = GK; P->mu = mu; P->delta = delta; P->Jc = Jc;
     P->dn = dn; P->grad = grad; P->active = active; P->iters = iters; P->status = status; P->conv = conv;
   }
   if (dc) *dc = cc;
@@ -1102,17 +1344,35 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
     }
   int m = prob->m;
   for (int i = 0; i < m * m; i++) c.R[i] = prob->R[i];
-  if (prob->kind == TOLG_DYN_DRONE) {  // traopt_dynamics.py:1250-1254
-    c.Pu[0 * 4 + 0] = 1; c.Pu[1 * 4 + 1] = 1; c.Pu[2 * 4 + 2] = 1; c.Pu[5 * 4 + 3] = 1;
-  } else {
-    for (int i = 0; i < 6; i++) c.Pu[i * 6 + i] = 1;
-  }
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < m; j++) {
-      double s = 0;
-      for (int k = 0; k < 6; k++) s += c.Jinv[6 * i + k] * c.Pu[k * m + j];
-      c.Bc[i * m + j] = s * prob->dt;  // F_u = Bt dt (traopt_dynamics.py:668-670, :850)
+  // J must be blkdiag(Ib, Jv) -- the structure the reference itself assumes (traopt_dynamics.py:640-665:
+  // "J: Inertia matrix, diag(I_b, m * I_3)"; G in f_x is built from Ib and m only)
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      if (prob->J[6 * i + j + 3] != 0.0 || prob->J[6 * (i + 3) + j] != 0.0) { delete h; return TOLG_E_ARG; }
+      c.Jv[3 * i + j] = prob->J[6 * (i + 3) + j + 3];
+      c.Ibinv[3 * i + j] = c.Jinv[6 * i + j];
+      c.Jvinv[3 * i + j] = c.Jinv[6 * (i + 3) + j + 3];
     }
+  // F_u = Bt dt (traopt_dynamics.py:668-670, :850; Pu of the drone :1250-1254)
+  for (int i = 0; i < 9; i++) { c.Bt[i] = c.Ibinv[i] * prob->dt; c.Bb[i] = 0; }
+  for (int i = 0; i < 3; i++) {
+    if (prob->kind == TOLG_DYN_DRONE) c.Bb[3 * i] = c.Jvinv[3 * i + 2] * prob->dt;
+    else for (int j = 0; j < 3; j++) c.Bb[3 * i + j] = c.Jvinv[3 * i + j] * prob->dt;
+  }
+  // gravity Jacobian L = J^-1 [[0,0],[skew(R^T e3), 0]] dt as a linear map of R^T e3
+  // (traopt_dynamics.py:1445-1458; no m*g)
+  for (int a = 0; a < 3; a++) {
+    double e3[3] = {0, 0, 0}, S[9];
+    e3[a] = 1.0;
+    S[0] = 0; S[1] = -e3[2]; S[2] = e3[1]; S[3] = e3[2]; S[4] = 0; S[5] = -e3[0]; S[6] = -e3[1]; S[7] = e3[0]; S[8] = 0;
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double sacc = 0;
+        if (j < 3 && c.grav != 0.0)
+          for (int k = 0; k < 3; k++) sacc += c.Jinv[6 * i + 3 + k] * S[3 * k + j];
+        c.Llin[a][6 * i + j] = sacc * prob->dt;
+      }
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   Consts* dc = nullptr;
   memset(&h->P, 0, sizeof h->P);
@@ -1204,11 +1464,13 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
 template <int M>
 static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear) {
   Timed t(h, st, 1);
-  hipLaunchKernelGGL(k_rollout_ms<M>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, alpha, linear);
+  dim3 grid((P.Bp + 63) / 64), blk(64);
+  if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha);
+  else if (alpha == 1.0) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha);
+  else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha);
   LAUNCH_CHECK();
   return 0;
 }
-
 template <int M>
 static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
