@@ -74,6 +74,26 @@ def test_linearize_backward_elementwise(kind, ms):
         assert float(r["mu_delta"][b, 0]) == o["mu"] and float(r["mu_delta"][b, 1]) == o["delta"]
 
 
+def test_full_inertia_block_general_path():
+    """Non-diagonal I_b / J_v take the general (non diagJ) code path of the dynamics."""
+    prob, x0_q, x0_xi, us0 = workloads.se3_tracking(3, N=30)
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(3, 3)) * 0.2
+    J = prob.J.copy()
+    J[:3, :3] = np.diag([0.5, 0.7, 0.9]) + A @ A.T
+    J[3:, 3:] = 1.3 * np.eye(3)
+    prob = TrackingProblem("se3", J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
+    solver = BatchedTrackingILQR(prob, 3)
+    r = solver.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=8, tol_grad_norm=0.0, tol_d_norm=0.0)
+    o = ob.fit_batch(_oracle_problem(prob), x0_q, x0_xi, us0, mode="ms", max_iter=8)
+    assert _rel(r.J_hist.cpu(), o["J_hist"]) < 1e-9
+    assert _rel(r.us.cpu(), o["us"]) < 1e-6
+    # coupling blocks between rotation and translation are rejected, as the reference's G assumes
+    Jbad = J.copy(); Jbad[0, 4] = Jbad[4, 0] = 0.01
+    with pytest.raises(RuntimeError, match="bad argument"):
+        BatchedTrackingILQR(TrackingProblem("se3", Jbad, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref), 3)
+
+
 def test_regularisation_loop_nonpd_branch():
     """Unpinned by any golden: an indefinite R makes Q_uu non-PD so the
     mu/delta schedule (traopt_controller.py:2977-2991) has to fire; the oracle is the reference."""

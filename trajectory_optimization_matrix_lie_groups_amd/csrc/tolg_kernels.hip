@@ -29,7 +29,7 @@ namespace tolg {
 // constants shared by the whole batch (device memory, read through the scalar cache)
 // ------------------------------------------------------------------------------------------------
 struct Consts {
-  int kind, m, N, pad;
+  int kind, m, N, diagJ;  // diagJ: Ib and Jv are diagonal (every reference script): 12 constants instead of 36
   double dt, mass, grav, pad2;
   double J[36], Jinv[36], Ib[9];
   // J = blkdiag(Ib, Jv) (checked in tolg_create): the 3x3 blocks and their inverses
@@ -95,7 +95,8 @@ enum {
   REC_M = 84,    // rollout left factor M = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 (quaternion xyzw, t)
   REC_C = 91,    // rollout offset c = xi_{i+1} - f_xi(x_i,u_i) + d_xi
   REC_A22 = 97,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
-  REC_F = 133
+  REC_LU = 133,  // l_u = 2 R u (m)
+  REC_F = 139
 };
 #define RIDX(i, f, b) ((((size_t)(i)) * REC_F + (size_t)(f)) * (size_t)P.Bp + (size_t)(b))
 #define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * 13 + (size_t)(j)) * (size_t)P.Bp + (size_t)(b))
@@ -156,7 +157,15 @@ TOLG_DEV State dyn_f(const Consts& C, const State& S, const double (&u)[M]) {
   Pose E = se3_exp(dt * S.w, dt * S.v);
   F.X = se3_project(se3_compose(S.X, E));
   // J = blkdiag(Ib, Jv): J xi = [Ib w; Jv v]
-  V3 y1 = mv33(C.Ib, S.w), y2 = mv33(C.Jv, S.v);
+  const bool dj = C.diagJ != 0;  // kernel-uniform
+  V3 y1, y2;
+  if (dj) {
+    y1 = v3(C.Ib[0] * S.w.x, C.Ib[4] * S.w.y, C.Ib[8] * S.w.z);
+    y2 = v3(C.Jv[0] * S.v.x, C.Jv[4] * S.v.y, C.Jv[8] * S.v.z);
+  } else {
+    y1 = mv33(C.Ib, S.w);
+    y2 = mv33(C.Jv, S.v);
+  }
   V3 top = cross(y1, S.w) + cross(y2, S.v);  // ad(xi)^T (J xi), upper half
   V3 bot = cross(y2, S.w);
   if (C.grav != 0.0) bot = bot + (C.mass * C.grav) * qrot_inv(S.X.q, v3(0, 0, -1.0));
@@ -164,8 +173,13 @@ TOLG_DEV State dyn_f(const Consts& C, const State& S, const double (&u)[M]) {
   top = top + v3(u[0], u[1], u[2]);
   if constexpr (M == 6) bot = bot + v3(u[3], u[4], u[5]);
   else bot = bot + v3(0, 0, u[3]);
-  F.w = S.w + dt * mv33(C.Ibinv, top);
-  F.v = S.v + dt * mv33(C.Jvinv, bot);
+  if (dj) {
+    F.w = S.w + v3(C.Bt[0] * top.x, C.Bt[4] * top.y, C.Bt[8] * top.z);  // Bt = Ib^-1 dt
+    F.v = S.v + dt * v3(C.Jvinv[0] * bot.x, C.Jvinv[4] * bot.y, C.Jvinv[8] * bot.z);
+  } else {
+    F.w = S.w + dt * mv33(C.Ibinv, top);
+    F.v = S.v + dt * mv33(C.Jvinv, bot);
+  }
   return F;
 }
 
@@ -360,6 +374,15 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         for (int k = 0; k < M; k++) l += u[a] * C.R[a * M + k] * u[k];
     }
     P.SC[(size_t)i * P.Bp + b] = l;
+    if (!term) {  // l_u = 2 R u (traopt_cost.py:792-804)
+#pragma unroll
+      for (int a = 0; a < M; a++) {
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sacc += 2.0 * C.R[a * M + k] * u[k];
+        P.REC[RIDX(i, REC_LU + a, b)] = sacc;
+      }
+    }
     double WJ[36];
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -589,6 +612,34 @@ template <int L>
 TOLG_DEV double bcast(double x) {  // value of x in lane L of this 16-lane row
   return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, false);
 }
+// acc[u] += P[u]@lane K * q for u < M (one k of a P Q product with M rows)
+template <int M, int K>
+TOLG_DEV void quu_acc(double (&acc)[M], const double (&Pm)[M], double q) {
+#ifndef TOLG_DPP_BUILTIN
+  if constexpr (M == 6) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %7, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %9, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %10, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %11, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5])
+                 : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(q), "n"(K));
+  } else {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                 : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(q), "n"(K));
+  }
+#else
+#pragma unroll
+  for (int u = 0; u < M; u++) acc[u] += bcast<K>(Pm[u]) * q;
+#endif
+}
 #ifdef TOLG_DPP_BUILTIN
 TOLG_DEV void rank1_bi(double (&acc)[12], double p, double q) {
   acc[0] += bcast<0>(p) * q; acc[1] += bcast<1>(p) * q; acc[2] += bcast<2>(p) * q; acc[3] += bcast<3>(p) * q;
@@ -617,6 +668,19 @@ TOLG_DEV void rank1_bi_023(double (&acc)[12], double p, double q) {
 // Cholesky of the symmetric part of Q (in place: on return the lower triangle of Q holds L with the
 // diagonal replaced by its reciprocal-free value, dinv the reciprocals).  Only the lower triangle
 // and diagonal of Q are read; the strict upper triangle keeps the original entries for lu_solve.
+// 1/sqrt(d) to double precision: v_rsq_f64 seed + two Goldschmidt/Newton refinements (no IEEE
+// division or sqrt sequence on the Cholesky critical path)
+TOLG_DEV double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);
+  return 2.0 * h;
+}
+// Cholesky of the symmetric part of Q.  L's strict lower triangle and dinv[j] = 1/L[j][j] are
+// produced (the diagonal itself is never needed by the solves).  Only Q[i][j], i >= j, is read.
 template <int M>
 TOLG_DEV bool chol_sym(double (&L)[M][M], const double (&Q)[M][M], double (&dinv)[M]) {
   bool ok = true;
@@ -626,12 +690,10 @@ TOLG_DEV bool chol_sym(double (&L)[M][M], const double (&Q)[M][M], double (&dinv
 #pragma unroll
     for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
     ok = ok && (d > 0.0);
-    double dj = sqrt(ok ? d : 1.0);
-    dinv[j] = 1.0 / dj;
-    L[j][j] = dj;
+    dinv[j] = rsqrt_nr(ok ? d : 1.0);
 #pragma unroll
     for (int i = j + 1; i < M; i++) {
-      double s = 0.5 * (Q[i][j] + Q[j][i]);
+      double s = Q[i][j];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
       L[i][j] = s * dinv[j];
@@ -766,10 +828,9 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
   // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
   // data right behind the request and undo the prefetch.
-  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], uu[M]; };
+  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M]; };
   auto load_knot = [&](int i, BwdIn& in) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
-    __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       in.t[r] = bld(rR, vT, r * sB);
@@ -787,7 +848,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       in.lb[r] = bld(rR, vb, (REC_LX + 6 + r) * sB);
     }
 #pragma unroll
-    for (int a = 0; a < M; a++) in.uu[a] = bld(rU, vb, a * sB);
+    for (int a = 0; a < M; a++) in.lu[a] = bld(rR, vb, (REC_LU + a) * sB);
   };
 
   auto step = [&](int i, const BwdIn& in) {
@@ -804,12 +865,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
     for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r] + W2col[r]; }
 #pragma unroll
-    for (int a = 0; a < M; a++) {
-      double sacc = 0;
-#pragma unroll
-      for (int k = 0; k < M; k++) sacc += 2.0 * C.R[a * M + k] * in.uu[k];
-      lu[a] = mvec * sacc;  // l_u = 2 R u rides in the vector columns
-    }
+    for (int a = 0; a < M; a++) lu[a] = mvec * in.lu[a];  // l_u = 2 R u rides in the vector columns
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
 #pragma unroll
@@ -869,26 +925,25 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
           Quh[u] = s;
           T[u] = m12 * tt;
         }
-        // Q_uu = 2R + T B: column per lane (lanes 0..M-1), then replicated to every lane
+        // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
         double Quu[M];
 #pragma unroll
-        for (int u = 0; u < M; u++) {
-          double s = Rcol[u];
-          s += bcast<6>(T[u]) * Bloc[0];
-          s += bcast<7>(T[u]) * Bloc[1];
-          s += bcast<8>(T[u]) * Bloc[2];
-          s += bcast<9>(T[u]) * Bloc[3];
-          s += bcast<10>(T[u]) * Bloc[4];
-          s += bcast<11>(T[u]) * Bloc[5];
-          Quu[u] = s;
-        }
+        for (int u = 0; u < M; u++) Quu[u] = Rcol[u];
+        quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
+        quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
+        // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
+        // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
 #pragma unroll
         for (int u = 0; u < M; u++) {
-          Qrep[u][0] = bcast<0>(Quu[u]); Qrep[u][1] = bcast<1>(Quu[u]);
-          Qrep[u][2] = bcast<2>(Quu[u]); Qrep[u][3] = bcast<3>(Quu[u]);
-          if constexpr (M > 4) { Qrep[u][4] = bcast<4>(Quu[u]); Qrep[u][5] = bcast<5>(Quu[u]); }
+          Qrep[u][0] = bcast<0>(Quu[u]);
+          if (u >= 1) Qrep[u][1] = bcast<1>(Quu[u]);
+          if (u >= 2) Qrep[u][2] = bcast<2>(Quu[u]);
+          if (u >= 3) Qrep[u][3] = bcast<3>(Quu[u]);
+          if constexpr (M > 4) {
+            if (u >= 4) Qrep[u][4] = bcast<4>(Quu[u]);
+            if (u >= 5) Qrep[u][5] = bcast<5>(Quu[u]);
+          }
         }
-        // is_pos_def(Q_uu + Q_uu^T)  (traopt_utilis.py:320-329) on the symmetric part
         bool pd = chol_sym<M>(Ls, Qrep, dinv);
         if (!pd) {
           delta = fmax(1.0, delta) * 2.0;
@@ -919,7 +974,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       for (int u = 0; u < M; u++) {
         Kl[u] = Kh[u];
 #pragma unroll
-        for (int k = 0; k < M; k++) Ac[u][k] = Qrep[u][k];
+        for (int k = 0; k < M; k++) Ac[u][k] = (k <= u) ? Qrep[u][k] : Qrep[k][u];
       }
       lu_solve<M>(Ac, Kl);
       chol_solve<M>(Ls, dinv, Kh);
@@ -1329,7 +1384,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->run_it = 0;
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
-  c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.dt = prob->dt;
+  c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
   memcpy(c.J, prob->J, sizeof c.J);
   if (host_inv6(prob->J, c.Jinv)) { delete h; return TOLG_E_SINGULAR; }
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.Ib[3 * i + j] = prob->J[6 * i + j];
@@ -1353,6 +1408,10 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
       c.Ibinv[3 * i + j] = c.Jinv[6 * i + j];
       c.Jvinv[3 * i + j] = c.Jinv[6 * (i + 3) + j + 3];
     }
+  c.diagJ = 1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (i != j && (c.Ib[3 * i + j] != 0.0 || c.Jv[3 * i + j] != 0.0)) c.diagJ = 0;
   // F_u = Bt dt (traopt_dynamics.py:668-670, :850; Pu of the drone :1250-1254)
   for (int i = 0; i < 9; i++) { c.Bt[i] = c.Ibinv[i] * prob->dt; c.Bb[i] = 0; }
   for (int i = 0; i < 3; i++) {

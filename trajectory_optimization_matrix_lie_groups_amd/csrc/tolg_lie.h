@@ -42,6 +42,14 @@ TOLG_DEV Q4 qnormalize(Q4 a) {
   double s = 1.0 / sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
   Q4 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; r.w = a.w * s; return r;
 }
+// Re-normalisation of a product of unit quaternions: |q|^2 = 1 + d with |d| ~ 1e-15, so
+// 1/sqrt(1+d) = 1 - d/2 + O(d^2) is exact to double precision without sqrt or division.
+TOLG_DEV Q4 qrenorm(Q4 a) {
+  double n2 = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  if (fabs(n2 - 1.0) > 1e-7) return qnormalize(a);
+  double s = 1.5 - 0.5 * n2;
+  Q4 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; r.w = a.w * s; return r;
+}
 // R(q) v for a unit quaternion
 TOLG_DEV V3 qrot(Q4 q, V3 v) {
   V3 u = v3(q.x, q.y, q.z);
@@ -147,15 +155,45 @@ TOLG_DEV V3 ljacinv_apply(V3 w, double c, V3 v) {
   return v - 0.5 * wv + c * cross(w, wv);
 }
 
+// Exp on SE(3) with ONE sincos: sin t = 2 s c, 1 - cos t = 2 s^2 for (s, c) = sincos(t/2)
 TOLG_DEV Pose se3_exp(V3 w, V3 v) {
   Pose X;
-  X.q = so3_exp(w);
-  X.t = ljac_apply(w, so3_coef(dot(w, w), false), v);
+  double th2 = dot(w, w);
+  SO3Coef k;
+  if (th2 > TOLG_EPS) {
+    double th = sqrt(th2), sh, ch;
+    sincos(0.5 * th, &sh, &ch);
+    double ith = 1.0 / th, i2 = ith * ith;
+    double so = sh * ith;
+    X.q.x = so * w.x; X.q.y = so * w.y; X.q.z = so * w.z; X.q.w = ch;
+    k.a = 2.0 * sh * sh * i2;
+    k.b = (th - 2.0 * sh * ch) * i2 * ith;
+  } else {
+    X.q = so3_exp(w);
+    k.a = 0.5; k.b = 0.0;
+  }
+  k.c1 = k.c2 = k.c3 = 0;
+  X.t = ljac_apply(w, k, v);
   return X;
 }
+// Log on SE(3); the V^-1 coefficient 1/t^2 - (1+cos t)/(2 t sin t) = 1/t^2 - cot(t/2)/(2t) comes
+// straight from the quaternion (cot(t/2) = |w|/|qv|): no sincos
 TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
-  w = so3_log(X.q);
-  v = ljacinv_apply(w, ljacinv_coef(dot(w, w)), X.t);
+  Q4 q = X.q;
+  double s2 = q.x * q.x + q.y * q.y + q.z * q.z, c, cl;
+  if (s2 > TOLG_EPS) {
+    double s = sqrt(s2);
+    double two = 2.0 * ((q.w < 0.0) ? atan2(-s, -q.w) : atan2(s, q.w));
+    double is = 1.0 / s, itw = 1.0 / two;
+    c = two * is;
+    cl = itw * itw - 0.5 * fabs(q.w) * is * fabs(itw);
+    if (two * two <= TOLG_EPS) cl = 0.0;  // manif's small-angle V^-1 = I - W/2
+  } else {
+    c = (q.w < 0.0) ? -2.0 : 2.0;
+    cl = 0.0;
+  }
+  w = v3(c * q.x, c * q.y, c * q.z);
+  v = ljacinv_apply(w, cl, X.t);
 }
 TOLG_DEV Pose se3_compose(Pose A, Pose B) {
   Pose C;
@@ -170,7 +208,7 @@ TOLG_DEV Pose se3_inverse(Pose A) {
   return B;
 }
 // the reference re-derives a unit quaternion from every matrix it receives: renormalise
-TOLG_DEV Pose se3_project(Pose A) { A.q = qnormalize(A.q); return A; }
+TOLG_DEV Pose se3_project(Pose A) { A.q = qrenorm(A.q); return A; }
 
 // ---- 3x3 helpers (row-major, fully unrolled so they stay in registers) ----------------------
 TOLG_DEV void skew(V3 w, double S[9]) {
