@@ -207,3 +207,46 @@ def test_full_size_properties_4096x200():
     # rotations stay orthonormal
     Rm = r1.xs_q[:, :, :3, :3]
     assert float((Rm.transpose(-1, -2) @ Rm - torch.eye(3, device=Rm.device, dtype=Rm.dtype)).abs().max()) < 1e-13
+
+
+def test_drone_ss_fit_reproduces_recorded_line_search(drone):
+    """Single shooting with the 13-alpha backtracking: the notebook's 9 iterations, including the
+    failed line search of iteration 8 (status NODESCENT, every trial cost recorded)."""
+    g, log, prob = drone
+    B = 2
+    solver = BatchedTrackingILQR(prob, B)
+    x0_q = np.repeat(g["q0"][None], B, 0); x0_xi = np.repeat(g["xi0"][None], B, 0)
+    r = solver.fit_batch(x0_q, x0_xi, None, mode="ss", n_iterations=200, tol_grad_norm=1e-12)
+    its = log["ss"]["iterations"]
+    J = r.J_hist.cpu().numpy(); G = r.grad_hist.cpu().numpy(); A = r.alpha_hist.cpu().numpy()
+    for b in range(B):
+        assert int(r.iters[b]) == 9 and int(r.status[b]) == 2 and int(r.converged[b]) == 0
+        for k, it in enumerate(its):
+            assert G[b, k] == pytest.approx(it["grad"], rel=1e-9)
+            assert J[b, k] == pytest.approx(it["cb_J"], rel=1e-11)
+            assert A[b, k] == pytest.approx(it["cb_alpha"], rel=1e-14)
+    o = ob.fit(_oracle_problem(prob), g["q0"], g["xi0"], g["us_init"], mode="ss", max_iter=200, tol_grad=1e-12)
+    assert _rel(r.us[0].cpu(), o["us"]) < 1e-6 and _rel(r.xs_q[0].cpu(), o["xs_q"]) < 1e-6
+
+
+@pytest.mark.parametrize("mode,line_search,rollout", [("ss", False, "nonlinear"), ("ss", False, "linear"),
+                                                      ("ms", True, "nonlinear"), ("ms", False, "linear"),
+                                                      ("ms", True, "linear")])
+def test_line_search_and_linear_rollout_variants_match_oracle(mode, line_search, rollout):
+    """Branches no recorded run exercises: the oracle is the reference."""
+    B, K = 6, 10
+    prob, x0_q, x0_xi, us0 = workloads.se3_tracking(B, N=50, R_scale=1e-3)
+    solver = BatchedTrackingILQR(prob, B)
+    r = solver.fit_batch(x0_q, x0_xi, us0, mode=mode, n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
+                         line_search=line_search, rollout=rollout)
+    o = ob.fit_batch(_oracle_problem(prob), x0_q, x0_xi, us0, mode=mode, max_iter=K, line_search=line_search,
+                     rollout=rollout)
+    it_g = r.iters.cpu().numpy()
+    np.testing.assert_array_equal(it_g, o["iters"])
+    np.testing.assert_array_equal(r.status.cpu().numpy(), o["status"])
+    Jg = r.J_hist.cpu().numpy()
+    for b in range(B):
+        n = it_g[b]
+        assert _rel(Jg[b, :n], o["J_hist"][b, :n]) < 1e-8
+    assert _rel(r.us.cpu(), o["us"]) < 1e-6
+    assert _rel(r.xs_xi.cpu(), o["xs_xi"]) < 1e-6

@@ -61,7 +61,18 @@ struct Params {
   double *J_hist, *grad_hist, *defect_hist, *alpha_hist, *mu_hist;
   int max_iter, pad;
   double tol_grad, tol_defect, max_reg;
+  // line search (SS backtracking, MS merit search): speculative candidates live in NSLOT slot buffers
+  double* slot_x;      // [NSLOT][N+1][13][Bp]
+  double* slot_u;      // [NSLOT][N][m][Bp]
+  double* Jtrial;      // [Bp][20] cost of the rollout with alpha_k
+  double* dtrial;      // [Bp][20] its defect norm (MS)
+  double* ecc;         // [Bp][2]  expected cost change of the linear alpha=1 rollout (MS)
+  double* dweight;     // [Bp][2]  current / previous defect weight (MS)
+  double* ls_alpha;    // [Bp]     last alpha tried this iteration
+  int* ls_accept;      // [Bp]     accepted alpha index or -1
+  int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
 };
+enum { NSLOT = 8, NALPHA_MS = 20, NALPHA_SS = 13 };
 
 // every array is knot-major [knot][field][Bp]: one knot of one field is a contiguous run over the batch
 #define SIDX(c, i, b) ((((size_t)(i)) * 13 + (size_t)(c)) * (size_t)P.Bp + (size_t)(b))
@@ -238,7 +249,7 @@ __global__ void k_init(Params P, const double* __restrict__ x0_q, const double* 
     for (int a = 0; a < P.m; a++) P.cur_u[UIDX(a, i, b)] = us_init[((size_t)bs * P.N + i) * P.m + a];
   if (i == 0) {
     P.mu[b] = 1.0; P.delta[b] = 2.0; P.active[b] = 1; P.iters[b] = 0; P.status[b] = 0; P.conv[b] = 0;
-    P.grad[b] = 0; P.Jc[b] = 0; P.dn[b] = 0;
+    P.grad[b] = 0; P.Jc[b] = 0; P.dn[b] = 0; P.ls_alpha[b] = 1.0; P.ls_accept[b] = -1; P.ls_slot[b] = -1;
   }
 }
 
@@ -260,7 +271,8 @@ __global__ void k_pack_traj(Params P, const double* __restrict__ xs_q, const dou
   if (i == 0) {
     P.mu[b] = mu_delta ? mu_delta[2 * bs] : 1.0;
     P.delta[b] = mu_delta ? mu_delta[2 * bs + 1] : 2.0;
-    P.active[b] = 1; P.iters[b] = 0; P.status[b] = 0; P.conv[b] = 0;
+    P.active[b] = 1; P.iters[b] = 0; P.status[b] = 0; P.conv[b] = 0; P.ls_alpha[b] = 1.0; P.ls_accept[b] = -1;
+    P.ls_slot[b] = -1;
   }
 }
 
@@ -536,7 +548,7 @@ __global__ void k_reduce(Params P, int it) {
   }
   if (P.J_hist) P.J_hist[(size_t)b * P.max_iter + it] = J;
   if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1) + it + 1] = dn;
-  if (P.alpha_hist) P.alpha_hist[(size_t)b * P.max_iter + it] = 1.0;
+  if (P.alpha_hist) P.alpha_hist[(size_t)b * P.max_iter + it] = P.ls_alpha[b];
   P.iters[b] = it + 1;
   if (!(J == J) || isinf(J)) { P.status[b] = TOLG_ST_NONFINITE; P.active[b] = 0; }
 }
@@ -1197,6 +1209,263 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Line search.  The reference tries alpha_k = 1.1^(-k^2) one after the other with a full rollout +
+// trajectory cost each (SS: traopt_controller.py:1972-1990, accept J_new < J_opt; MS:
+// :2549-2590, Armijo test on the merit J + w ||d||).  Here a stage evaluates several alphas of
+// every still-undecided trajectory at once (one thread per (trajectory, alpha), candidates kept in
+// slot buffers), then the first alpha that passes -- in the reference's order -- wins.
+// ------------------------------------------------------------------------------------------------
+TOLG_DEV double ls_alpha_k(int k) { return pow(1.1, -(double)(k * k)); }
+
+// stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738)
+template <int M>
+TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, const State& S, const double (&u)[M], bool term) {
+  const double* r = P.ref + 13 * (size_t)i;
+  Pose Xr;
+  Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
+  Xr.t = v3(r[4], r[5], r[6]);
+  V3 ew, ev;
+  se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+  const double* W1 = term ? C.P1 : C.W1;
+  const double* W2 = term ? C.P2 : C.W2;
+  double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
+  double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
+  double l = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { s1 += W1[6 * a + k] * e[k]; s2 += W2[6 * a + k] * ve[k]; }
+    l += e[a] * s1 + ve[a] * s2;
+  }
+  if (!term) {
+#pragma unroll
+    for (int a = 0; a < M; a++)
+#pragma unroll
+      for (int k = 0; k < M; k++) l += u[a] * C.R[a * M + k] * u[k];
+  }
+  return l;
+}
+
+// one thread per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm
+template <int M, bool MS, bool LINEAR>
+__global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslots) {
+  const Consts& C = *P.c;
+  const int b = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
+  if (b >= P.Bp || slot >= nslots) return;
+  if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  const int N = P.N, ai = a0 + slot;
+  const double alpha = ls_alpha_k(ai);
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp,
+               gStride = (size_t)13 * M * P.Bp;
+  double* sx = P.slot_x + (size_t)slot * stStride * (N + 1);
+  double* su = P.slot_u + (size_t)slot * uStride * N;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  store_state_b(mkbuf(sx, 13 * sB), vb, sB, Sn);
+  double J = 0, d2 = 0;
+  for (int i = 0; i < N; i++) {
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+    __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB);
+    State So = load_state_b(mkbuf(P.cur + stStride * i, 13 * sB), vb, sB);
+    V3 ew, ev;
+    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+    double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                    Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+    double u[M], un[M], du[M];
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      double sacc = alpha * bld(rG, vb, (unsigned)(a * 13 + 12) * sB);
+#pragma unroll
+      for (int k = 0; k < 12; k++) sacc += bld(rG, vb, (unsigned)(a * 13 + k) * sB) * e[k];
+      u[a] = bld(rU, vb, a * sB);
+      du[a] = sacc;
+      un[a] = u[a] + sacc;
+    }
+    J += knot_cost<M>(P, C, i, Sn, un, false);
+    State Nx;
+    if constexpr (!LINEAR) {
+      State Fn = dyn_f<M>(C, Sn, un);
+      if constexpr (MS) {
+        double d[12];
+#pragma unroll
+        for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+        State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, u);
+        Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
+                              se3_inverse(Fo.X));
+        Nx.X = se3_project(se3_compose(Mx, Fn.X));
+        Nx.w = (Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8])) + Fn.w;
+        Nx.v = (Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11])) + Fn.v;
+      } else {
+        Nx = Fn;  // SS: x^_{i+1} = f(x^_i, u^_i) (traopt_controller.py:2073-2080)
+      }
+      if constexpr (MS) {  // new defect Log(x^_{i+1}^-1 f_q(x^_i,u^_i)), f_xi - xi^_{i+1}
+        V3 dw, dv;
+        se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+        V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
+        d2 += dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
+      }
+    } else {
+      double lin[12], d[12];
+      fx_apply<M>(P, C, i, b, e, du, lin);
+#pragma unroll
+      for (int a = 0; a < 12; a++) d[a] = MS ? alpha * bld(rR, vb, (REC_D + a) * sB) : 0.0;
+      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+      Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
+      Nx.X = se3_project(se3_compose(Sx.X, D));
+      Nx.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
+      Nx.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
+      if constexpr (MS) {
+        State Fn = dyn_f<M>(C, Sn, un);
+        V3 dw, dv;
+        se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+        V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
+        d2 += dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
+      }
+    }
+    __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB);
+#pragma unroll
+    for (int a = 0; a < M; a++) bst(rSU, vb, a * sB, un[a]);
+    store_state_b(mkbuf(sx + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+    Sn = Nx;
+  }
+  double uz[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) uz[a] = 0;
+  J += knot_cost<M>(P, C, N, Sn, uz, true);
+  P.Jtrial[(size_t)b * 20 + ai] = J;
+  P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
+}
+
+// MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
+// _expected_cost_change (:2756-2769), _update_defect_weight (:2774-2788)
+template <int M>
+__global__ __launch_bounds__(64) void k_expected_change(Params P) {
+  const Consts& C = *P.c;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.Bp || !P.active[b]) return;
+  const int N = P.N;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  double c1 = 0, c2 = 0;
+  for (int i = 0; i <= N; i++) {
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    State So = load_state_b(mkbuf(P.cur + stStride * i, 13 * sB), vb, sB);
+    V3 ew, ev;
+    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+    double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                    Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+    // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
+    const double* W2 = (i == N) ? C.P2 : C.W2;
+#pragma unroll
+    for (int a = 0; a < 12; a++) c1 += bld(rR, vb, (REC_LX + a) * sB) * e[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        c2 += e[a] * bld(rR, vb, (unsigned)(REC_LXX + sym6(a, k)) * sB) * e[k];
+        c2 += e[6 + a] * 2.0 * W2[6 * a + k] * e[6 + k];
+      }
+    if (i == N) break;
+    __amdgpu_buffer_rsrc_t rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+    double du[M];
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      double sacc = bld(rG, vb, (unsigned)(a * 13 + 12) * sB);
+#pragma unroll
+      for (int k = 0; k < 12; k++) sacc += bld(rG, vb, (unsigned)(a * 13 + k) * sB) * e[k];
+      du[a] = sacc;
+    }
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      c1 += bld(rR, vb, (REC_LU + a) * sB) * du[a];
+#pragma unroll
+      for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
+    }
+    double lin[12], d[12];
+    fx_apply<M>(P, C, i, b, e, du, lin);
+#pragma unroll
+    for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+    State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+    Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
+    Sn.X = se3_project(se3_compose(Sx.X, D));
+    Sn.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
+    Sn.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
+  }
+  P.ecc[2 * b] = c1;
+  P.ecc[2 * b + 1] = c2;
+  double dn = P.dn[b], wprev = P.dweight[2 * b + 1], w;
+  if (dn < 1e-12) w = wprev;  // _defect_kappa
+  else w = fmax(10.0, 10.0 + fabs(c1 + 0.5 * c2) / ((1.0 - 0.5) * dn));
+  P.dweight[2 * b] = w;
+  P.dweight[2 * b + 1] = w;
+}
+
+__global__ void k_ls_begin(Params P, int first_fit_iteration) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp) return;
+  P.ls_accept[b] = -1;
+  P.ls_slot[b] = -1;
+  P.ls_alpha[b] = 1.0;
+  if (first_fit_iteration) { P.dweight[2 * b] = 10.0; P.dweight[2 * b + 1] = 10.0; }  // _defect_mu0
+}
+
+// first alpha (in the reference's order) of this stage that passes the acceptance test
+template <bool MS>
+__global__ void k_ls_select(Params P, int a0, int nslots) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp || !P.active[b] || P.ls_accept[b] >= 0) return;
+  const double J0 = P.Jc[b], dn = P.dn[b];
+  for (int s = 0; s < nslots; s++) {
+    const int ai = a0 + s;
+    const double alpha = ls_alpha_k(ai), Jn = P.Jtrial[(size_t)b * 20 + ai];
+    P.ls_alpha[b] = alpha;  // "alpha" the callback sees is the last one tried (App. C-Q12)
+    bool ok;
+    if (MS) {
+      const double w = P.dweight[2 * b], c1 = P.ecc[2 * b], c2 = P.ecc[2 * b + 1];
+      const double merit = J0 + w * dn, merit_new = Jn + w * P.dtrial[(size_t)b * 20 + ai];
+      const double Jexp = alpha * c1 + 0.5 * alpha * alpha * c2;
+      ok = (merit_new - merit) < 0.05 * (Jexp - alpha * w * dn);
+    } else {
+      ok = Jn < J0;
+    }
+    if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = s; return; }
+  }
+}
+
+__global__ void k_ls_copy(Params P) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  const int s = P.ls_slot[b];
+  if (s < 0 || !P.active[b]) return;
+  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)P.m * P.Bp;
+  const double* sx = P.slot_x + (size_t)s * stStride * (P.N + 1);
+  const double* su = P.slot_u + (size_t)s * uStride * P.N;
+  for (int c = 0; c < 13; c++) P.cand[SIDX(c, i, b)] = sx[SIDX(c, i, b)];
+  if (i < P.N)
+    for (int c = 0; c < P.m; c++) P.cand_u[UIDX(c, i, b)] = su[UIDX(c, i, b)];
+}
+__global__ void k_ls_clear_slot(Params P) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < P.Bp) P.ls_slot[b] = -1;
+}
+// trajectories without an acceptable step: callback with the unchanged cost, then stop
+// (traopt_controller.py:2621-2633, :1996-2007)
+__global__ void k_ls_finish(Params P, int it) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp || !P.active[b] || P.ls_accept[b] >= 0) return;
+  P.status[b] = TOLG_ST_NODESCENT;
+  P.active[b] = 0;
+  P.iters[b] = it + 1;
+  if (b >= P.B) return;
+  if (P.J_hist) P.J_hist[(size_t)b * P.max_iter + it] = P.Jc[b];
+  if (P.alpha_hist) P.alpha_hist[(size_t)b * P.max_iter + it] = P.ls_alpha[b];
+  if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1) + it + 1] = P.dn[b];
+}
+
 // export kernels for the unit-parity entry point
 __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restrict__ d, double* __restrict__ lx,
                              double* __restrict__ lxx11, double* __restrict__ kk, double* __restrict__ K) {
@@ -1330,7 +1599,18 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* iters = c.take<int>(B);
   int* status = c.take<int>(B);
   int* conv = c.take<int>(B);
+  double* slot_x = c.take<double>((size_t)NSLOT * 13 * (N + 1) * B);
+  double* slot_u = c.take<double>((size_t)NSLOT * m * N * B);
+  double* Jtrial = c.take<double>(20 * B);
+  double* dtrial = c.take<double>(20 * B);
+  double* ecc = c.take<double>(2 * B);
+  double* dweight = c.take<double>(2 * B);
+  double* ls_alpha = c.take<double>(B);
+  int* ls_accept = c.take<int>(B);
+  int* ls_slot = c.take<int>(B);
   if (P) {
+    P->slot_x = slot_x; P->slot_u = slot_u; P->Jtrial = Jtrial; P->dtrial = dtrial; P->ecc = ecc;
+    P->dweight = dweight; P->ls_alpha = ls_alpha; P->ls_accept = ls_accept; P->ls_slot = ls_slot;
     P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
     P->REC = REC; P->SC = SC; P->SD = SD; P->GK = GK; P->mu = mu; P->delta = delta; P->Jc = Jc;
     P->dn = dn; P->grad = grad; P->active = active; P->iters = iters; P->status = status; P->conv = conv;
@@ -1521,23 +1801,78 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
   return 0;
 }
 template <int M>
-static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear) {
+static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear, int ms = 1) {
   Timed t(h, st, 1);
   dim3 grid((P.Bp + 63) / 64), blk(64);
   if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha);
-  else if (alpha == 1.0) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha);
+  else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha);
   else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha);
   LAUNCH_CHECK();
   return 0;
 }
+template <int M, bool MS>
+static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a0, int n, int linear) {
+  {
+    Timed t(h, st, 1);
+    dim3 grid((P.Bp + 63) / 64, n), blk(64);
+    if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true>), grid, blk, 0, st, P, a0, n);
+    else hipLaunchKernelGGL((k_rollout_eval<M, MS, false>), grid, blk, 0, st, P, a0, n);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n);
+  LAUNCH_CHECK();
+  size_t nn = (size_t)(P.N + 1) * P.Bp;
+  hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// iLQR_Tracking_SE3_MS loop body (traopt_controller.py:2522-2626)
 template <int M>
 static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
-    if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
+    if (!opt->line_search) {
+      if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
+    } else {
+      hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_expected_change<M>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+      LAUNCH_CHECK();
+      // 20 alphas in four stages: the common first-try accept costs one rollout
+      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
+      hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+      LAUNCH_CHECK();
+    }
     // the accepted candidate becomes the nominal trajectory while it is re-linearised
     if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// iLQR_Tracking_SE3 loop body (traopt_controller.py:1926-2007): gradient test and backward pass share
+// one sweep; 13-alpha backtracking in three speculative stages
+template <int M>
+static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+  int rc;
+  for (int it = it0; it < it0 + n; it++) {
+    if ((rc = run_backward<M>(h, P, st, it, 0))) return rc;
+    hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
+    LAUNCH_CHECK();
+    if ((rc = run_ls_stage<M, false>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
+    hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+    LAUNCH_CHECK();
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0))) return rc;
     hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
   }
@@ -1550,18 +1885,23 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
                                 void* stream) {
   if (!h || !opt || B < 1 || B > h->max_batch || !d_x0_q || !d_x0_xi || !d_us_init) return TOLG_E_ARG;
   if (opt->max_iter < 0) return TOLG_E_ARG;
-  if (opt->mode != TOLG_MODE_MS) return TOLG_E_ARG;  // SS arrives with the speculative line search
-  if (opt->line_search) return TOLG_E_ARG;
+  if (opt->mode != TOLG_MODE_MS && opt->mode != TOLG_MODE_SS) return TOLG_E_ARG;
+  const int ms = opt->mode == TOLG_MODE_MS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
   P.J_hist = d_J_hist; P.grad_hist = d_grad_hist; P.defect_hist = d_defect_hist; P.alpha_hist = d_alpha_hist;
   P.mu_hist = d_mu_hist; P.max_iter = opt->max_iter; P.tol_grad = opt->tol_grad; P.tol_defect = opt->tol_defect;
   P.max_reg = opt->max_reg;
   size_t n = (size_t)(P.N + 1) * P.Bp;
-  hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, 1);
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, ms);
   LAUNCH_CHECK();
-  int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 1)
-                      : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 1);
+  if (!ms) {  // SS: dynamically feasible initial trajectory (_init_rollout, traopt_controller.py:2015-2028)
+    if (P.m == 4) hipLaunchKernelGGL(k_init_rollout<4>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(k_init_rollout<6>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+    LAUNCH_CHECK();
+  }
+  int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms)
+                      : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms);
   if (rc) return rc;
   hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, -1);
   LAUNCH_CHECK();
@@ -1573,8 +1913,13 @@ extern "C" int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream)
   if (!h || !h->running || n_iter < 0) return TOLG_E_ARG;
   if (h->run_it + n_iter > h->run_opt.max_iter) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = (h->run.m == 4) ? iterate_ms<4>(h, h->run, &h->run_opt, st, h->run_it, n_iter)
-                           : iterate_ms<6>(h, h->run, &h->run_opt, st, h->run_it, n_iter);
+  int rc;
+  if (h->run_opt.mode == TOLG_MODE_MS)
+    rc = (h->run.m == 4) ? iterate_ms<4>(h, h->run, &h->run_opt, st, h->run_it, n_iter)
+                         : iterate_ms<6>(h, h->run, &h->run_opt, st, h->run_it, n_iter);
+  else
+    rc = (h->run.m == 4) ? iterate_ss<4>(h, h->run, &h->run_opt, st, h->run_it, n_iter)
+                         : iterate_ss<6>(h, h->run, &h->run_opt, st, h->run_it, n_iter);
   if (rc) return rc;
   h->run_it += n_iter;
   return 0;
@@ -1642,10 +1987,9 @@ extern "C" int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_r
 extern "C" int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear, double alpha, int32_t B,
                             double* d_xs_q_new, double* d_xs_xi_new, double* d_us_new, void* stream) {
   if (!h || B < 1 || B > h->max_batch) return TOLG_E_ARG;
-  if (!ms) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
-  int rc = (P.m == 4) ? run_rollout_ms<4>(h, P, st, alpha, rollout_linear) : run_rollout_ms<6>(h, P, st, alpha, rollout_linear);
+  int rc = (P.m == 4) ? run_rollout_ms<4>(h, P, st, alpha, rollout_linear, ms) : run_rollout_ms<6>(h, P, st, alpha, rollout_linear, ms);
   if (rc) return rc;
   size_t n = (size_t)(P.N + 1) * P.Bp;
   hipLaunchKernelGGL(k_unpack_traj, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, P.cand, P.cand_u, d_xs_q_new,
