@@ -53,7 +53,7 @@ typedef struct {
 typedef struct {
   int32_t mode;            /* TOLG_MODE_MS | TOLG_MODE_SS */
   int32_t max_iter;        /* n_iterations */
-  int32_t line_search;     /* MS only */
+  int32_t line_search;     /* MS: merit-function search (:2549-2590); SS always backtracks */
   int32_t rollout_linear;  /* rollout == 'linear' */
   double tol_grad;         /* tol_grad_norm */
   double tol_defect;       /* tol_d_norm (MS) */
@@ -103,6 +103,24 @@ int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const 
 int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream);
 int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
                    int32_t* d_status, int32_t* d_converged, void* stream);
+
+/* Augmented-Lagrangian box input constraint lb <= u <= ub -- replaces ALConstrainedCost wrapping the
+ * tracking cost with an InputConstraint (traoptlibrary/traopt_cost.py:1173-1320,
+ * traoptlibrary/traopt_constraints.py:66-169).  d_lb/d_ub [m]; d_lambda, d_imu [B][N][2m] (multipliers
+ * and the diagonal of I_mu for g = [lb - u; u - ub]; the terminal knot has g = 0).  The buffers stay
+ * caller-owned and are read by every later solve on this handle; d_lb = NULL switches AL off. */
+int tolg_set_al(tolg_handle_t h, const double* d_lb, const double* d_ub, const double* d_lambda,
+                const double* d_imu);
+
+/* One outer iteration of AL_iLQR_Tracking_SE3_MS (traoptlibrary/traopt_controller.py:3242-3250,
+ * :3270-3290) for B independent problems on the controls d_us [B][N][m] of the inner solve:
+ * d_maxviol[b] = max_k g_k over all knots; if it is below tol_constr the problem is marked in
+ * d_al_converged[b] and left alone (now and in later calls); otherwise
+ * lambda <- max(0, lambda + I_mu g), mu <- min(mu_scale*mu, mu_max),
+ * I_mu <- (g < 0 and lambda_new == 0) ? 0 : mu_new. */
+int tolg_al_update(tolg_handle_t h, int32_t B, const double* d_us, const double* d_lb, const double* d_ub,
+                   double* d_lambda, double* d_imu, double* d_mu, double mu_scale, double mu_max,
+                   double tol_constr, double* d_maxviol, int32_t* d_al_converged, void* stream);
 
 /* One linearisation + backward pass on given trajectories (unit-parity entry point): replaces
  * iLQR_Tracking_SE3_MS._linearization + _backward_pass + _gradient_wrt_control

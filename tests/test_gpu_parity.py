@@ -250,3 +250,56 @@ def test_line_search_and_linear_rollout_variants_match_oracle(mode, line_search,
         assert _rel(Jg[b, :n], o["J_hist"][b, :n]) < 1e-8
     assert _rel(r.us.cpu(), o["us"]) < 1e-6
     assert _rel(r.xs_xi.cpu(), o["xs_xi"]) < 1e-6
+
+
+def _al_oracle(prob, x0_q, x0_xi, us0, lb, ub, n_al, n_ilqr, tol_constr, mu0=1e-2, mu_scale=10.0, mu_max=1e8):
+    """AL_iLQR_Tracking_SE3_MS.fit restated with the oracle as inner solver
+    (reference traoptlibrary/traopt_controller.py:3218-3293; the reference class itself does not
+    run at HEAD -- SURVEY App. C-Q7 -- so this is the specification: parity unpinned)."""
+    N, m = prob.N, prob.m
+    lam = np.zeros((N, 2 * m)); imu = np.full((N, 2 * m), mu0); mu = mu0
+    for it in range(n_al):
+        op = ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref,
+                              al=dict(lb=lb, ub=ub, lam=lam, imu=imu))
+        o = ob.fit(op, x0_q, x0_xi, us0, mode="ms", max_iter=n_ilqr, tol_grad=1e-6, tol_defect=1e-6)
+        g = np.concatenate([lb[None] - o["us"], o["us"] - ub[None]], axis=1)
+        if max(g.max(), 0.0) < tol_constr:
+            return o, lam, imu, mu, it + 1
+        mu_new = min(mu * mu_scale, mu_max)
+        lam_new = np.clip(lam + imu * g, 0.0, None)
+        imu = np.where((g < 0.0) & (lam_new == 0.0), 0.0, mu_new)
+        lam, mu = lam_new, mu_new
+    return o, lam, imu, mu, n_al
+
+
+def test_augmented_lagrangian_input_box_matches_restated_outer_loop():
+    """BASELINE config 4 shape (SE3 AL-DDP multiple shooting with input box constraints), small."""
+    from scipy.linalg import expm
+    N, dt, B = 40, 0.01, 3
+    xi_c = np.array([0.0, 0.0, 1.0, 2.0, 0.0, 0.2])
+    hat = np.zeros((4, 4)); hat[:3, :3] = [[0, -1.0, 0], [1.0, 0, 0], [0, 0, 0]]; hat[:3, 3] = xi_c[3:]
+    q_ref = np.empty((N + 1, 4, 4)); q_ref[0] = np.eye(4)
+    for i in range(N):
+        q_ref[i + 1] = q_ref[i] @ expm(hat * dt)
+    xi_ref = np.repeat(xi_c[None], N + 1, 0)
+    Q = np.diag([10.0, 10, 10, 1, 1, 1, 1, 1, 1, 1, 1, 1])
+    prob = TrackingProblem("se3", np.diag([0.5, 0.7, 0.9, 1, 1, 1.0]), dt, Q, np.eye(6) * 1e-3, 10 * Q, q_ref, xi_ref)
+    q0 = np.eye(4); q0[:3, 3] = [-0.3, -0.3, -0.1]
+    xi0 = np.array([0, 0, 0.1, 2.0, 0, 0.2])
+    x0_q, x0_xi = workloads.perturbed_batch(q0, xi0, B, 0.1 * np.ones(6), 0.05, seed=3)
+    us0 = np.zeros((B, N, 6))
+    lb = -4.0 * np.ones(6); ub = 4.0 * np.ones(6)
+    solver = BatchedTrackingILQR(prob, B)
+    # the unconstrained solution must violate the box, otherwise the test is vacuous
+    free = solver.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=60)
+    assert float(free.us.abs().max()) > 6.0
+    res, info = solver.al_fit_batch(x0_q, x0_xi, us0, lb, ub, n_al_iters=8, n_ilqr_iters=60, tol_constr=1e-2)
+    assert int(info["al_converged"].sum()) == B
+    assert float(res.us.max()) < 4.0 + 1e-2 and float(res.us.min()) > -4.0 - 1e-2
+    for b in range(B):
+        o, lam, imu, mu, n_outer = _al_oracle(prob, x0_q[b], x0_xi[b], us0[b], lb, ub, 8, 60, 1e-2)
+        assert _rel(res.us[b].cpu(), o["us"]) < 1e-6
+        assert _rel(res.xs_xi[b].cpu(), o["xs_xi"]) < 1e-6
+        assert _rel(info["lmbd"][b].cpu(), lam) < 1e-6
+        assert float(info["mu"][b]) == pytest.approx(mu)
+        np.testing.assert_array_equal(info["Imu"][b].cpu().numpy() == 0.0, imu == 0.0)

@@ -71,6 +71,11 @@ struct Params {
   double* ls_alpha;    // [Bp]     last alpha tried this iteration
   int* ls_accept;      // [Bp]     accepted alpha index or -1
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
+  // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
+  const double* al_lb;      // [m] or null (= AL off)
+  const double* al_ub;      // [m]
+  const double* al_lambda;  // [B][N][2m]
+  const double* al_imu;     // [B][N][2m] diagonal of I_mu
 };
 enum { NSLOT = 8, NALPHA_MS = 20, NALPHA_SS = 13 };
 
@@ -106,8 +111,9 @@ enum {
   REC_M = 84,    // rollout left factor M = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 (quaternion xyzw, t)
   REC_C = 91,    // rollout offset c = xi_{i+1} - f_xi(x_i,u_i) + d_xi
   REC_A22 = 97,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
-  REC_LU = 133,  // l_u = 2 R u (m)
-  REC_F = 139
+  REC_LU = 133,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
+  REC_LUU = 139, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
+  REC_F = 145
 };
 #define RIDX(i, f, b) ((((size_t)(i)) * REC_F + (size_t)(f)) * (size_t)P.Bp + (size_t)(b))
 #define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * 13 + (size_t)(j)) * (size_t)P.Bp + (size_t)(b))
@@ -385,16 +391,37 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 #pragma unroll
         for (int k = 0; k < M; k++) l += u[a] * C.R[a * M + k] * u[k];
     }
-    P.SC[(size_t)i * P.Bp + b] = l;
     if (!term) {  // l_u = 2 R u (traopt_cost.py:792-804)
+      double lu[M], luu[M];
 #pragma unroll
       for (int a = 0; a < M; a++) {
         double sacc = 0;
 #pragma unroll
         for (int k = 0; k < M; k++) sacc += 2.0 * C.R[a * M + k] * u[k];
-        P.REC[RIDX(i, REC_LU + a, b)] = sacc;
+        lu[a] = sacc;
+        luu[a] = 0.0;
+      }
+      if (P.al_lb) {
+        // LA = l + lambda^T g + g^T I_mu g / 2, g = [lb - u; u - ub], g_u = [-I; I]
+        // (traopt_cost.py:1219-1224, :1262-1266, :1302-1306; traopt_constraints.py:130-133, :167-169)
+        const int bs = b < P.B ? b : P.B - 1;
+        const double* lam = P.al_lambda + ((size_t)bs * P.N + i) * 2 * M;
+        const double* imu = P.al_imu + ((size_t)bs * P.N + i) * 2 * M;
+#pragma unroll
+        for (int a = 0; a < M; a++) {
+          double g1 = P.al_lb[a] - u[a], g2 = u[a] - P.al_ub[a];
+          l += lam[a] * g1 + lam[M + a] * g2 + 0.5 * (g1 * imu[a] * g1 + g2 * imu[M + a] * g2);
+          lu[a] += -(lam[a] + imu[a] * g1) + (lam[M + a] + imu[M + a] * g2);
+          luu[a] = imu[a] + imu[M + a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < M; a++) {
+        P.REC[RIDX(i, REC_LU + a, b)] = lu[a];
+        P.REC[RIDX(i, REC_LUU + a, b)] = luu[a];
       }
     }
+    P.SC[(size_t)i * P.Bp + b] = l;
     double WJ[36];
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -810,6 +837,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   const unsigned vT = vb + (unsigned)fT * sB, vM = vb + (unsigned)fM * sB, vBt = vb + (unsigned)fB * sB;
   const unsigned vG = vb + (unsigned)(j < 13 ? j : 12) * sB;
+  const unsigned vUU = vb + (unsigned)(REC_LUU + (j < M ? j : 0)) * sB;
   unsigned vL[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) vL[r] = vb + (unsigned)fL[r] * sB;
@@ -840,7 +868,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
   // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
   // data right behind the request and undo the prefetch.
-  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M]; };
+  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M], luu; };
   auto load_knot = [&](int i, BwdIn& in) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
 #pragma unroll
@@ -861,6 +889,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
 #pragma unroll
     for (int a = 0; a < M; a++) in.lu[a] = bld(rR, vb, (REC_LU + a) * sB);
+    in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
   };
 
   auto step = [&](int i, const BwdIn& in) {
@@ -940,7 +969,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
         double Quu[M];
 #pragma unroll
-        for (int u = 0; u < M; u++) Quu[u] = Rcol[u];
+        for (int u = 0; u < M; u++) Quu[u] = Rcol[u] + ((j == u) ? in.luu : 0.0);
         quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
         quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
         // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
@@ -1220,7 +1249,7 @@ TOLG_DEV double ls_alpha_k(int k) { return pow(1.1, -(double)(k * k)); }
 
 // stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738)
 template <int M>
-TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, const State& S, const double (&u)[M], bool term) {
+TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const State& S, const double (&u)[M], bool term) {
   const double* r = P.ref + 13 * (size_t)i;
   Pose Xr;
   Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
@@ -1244,6 +1273,16 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, const State& 
     for (int a = 0; a < M; a++)
 #pragma unroll
       for (int k = 0; k < M; k++) l += u[a] * C.R[a * M + k] * u[k];
+    if (P.al_lb) {
+      const int bs = b < P.B ? b : P.B - 1;
+      const double* lam = P.al_lambda + ((size_t)bs * P.N + i) * 2 * M;
+      const double* imu = P.al_imu + ((size_t)bs * P.N + i) * 2 * M;
+#pragma unroll
+      for (int a = 0; a < M; a++) {
+        double g1 = P.al_lb[a] - u[a], g2 = u[a] - P.al_ub[a];
+        l += lam[a] * g1 + lam[M + a] * g2 + 0.5 * (g1 * imu[a] * g1 + g2 * imu[M + a] * g2);
+      }
+    }
   }
   return l;
 }
@@ -1283,7 +1322,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
       du[a] = sacc;
       un[a] = u[a] + sacc;
     }
-    J += knot_cost<M>(P, C, i, Sn, un, false);
+    J += knot_cost<M>(P, C, i, b, Sn, un, false);
     State Nx;
     if constexpr (!LINEAR) {
       State Fn = dyn_f<M>(C, Sn, un);
@@ -1333,7 +1372,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
   double uz[M];
 #pragma unroll
   for (int a = 0; a < M; a++) uz[a] = 0;
-  J += knot_cost<M>(P, C, N, Sn, uz, true);
+  J += knot_cost<M>(P, C, N, b, Sn, uz, true);
   P.Jtrial[(size_t)b * 20 + ai] = J;
   P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
 }
@@ -1383,6 +1422,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
       c1 += bld(rR, vb, (REC_LU + a) * sB) * du[a];
 #pragma unroll
       for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
+      c2 += du[a] * bld(rR, vb, (REC_LUU + a) * sB) * du[a];
     }
     double lin[12], d[12];
     fx_apply<M>(P, C, i, b, e, du, lin);
@@ -1466,6 +1506,38 @@ __global__ void k_ls_finish(Params P, int it) {
   if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1) + it + 1] = P.dn[b];
 }
 
+// Augmented-Lagrangian outer update (AL_iLQR_Tracking_SE3_MS._al_update_param,
+// traopt_controller.py:3270-3290) and the constraint evaluation of :3242-3250, one thread per
+// trajectory: lambda <- max(0, lambda + I_mu g), mu <- min(mu_scale mu, mu_max),
+// I_mu <- 0 where (g < 0 and lambda_new == 0) else mu_new; maxviol = max g over all knots.
+__global__ void k_al_update(int B, int N, int m, const double* __restrict__ us, const double* __restrict__ lb,
+                            const double* __restrict__ ub, double* __restrict__ lam, double* __restrict__ imu,
+                            double* __restrict__ mu, double mu_scale, double mu_max, double tol_constr,
+                            double* __restrict__ maxviol, int* __restrict__ al_conv) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || al_conv[b]) return;  // a converged problem keeps its multipliers
+  double mv = 0.0;                   // the terminal knot contributes g = 0
+  for (int i = 0; i < N; i++) {
+    const double* u = us + ((size_t)b * N + i) * m;
+    for (int k = 0; k < 2 * m; k++) mv = fmax(mv, (k < m) ? lb[k] - u[k] : u[k - m] - ub[k - m]);
+  }
+  maxviol[b] = mv;
+  if (mv < tol_constr) { al_conv[b] = 1; return; }  // traopt_controller.py:3250, :3262-3263
+  const double mu_new = fmin(mu[b] * mu_scale, mu_max);
+  for (int i = 0; i < N; i++) {
+    const double* u = us + ((size_t)b * N + i) * m;
+    double* l = lam + ((size_t)b * N + i) * 2 * m;
+    double* im = imu + ((size_t)b * N + i) * 2 * m;
+    for (int k = 0; k < 2 * m; k++) {
+      double g = (k < m) ? lb[k] - u[k] : u[k - m] - ub[k - m];
+      double ln = fmax(0.0, l[k] + im[k] * g);
+      l[k] = ln;
+      im[k] = (g < 0.0 && ln == 0.0) ? 0.0 : mu_new;
+    }
+  }
+  mu[b] = mu_new;
+}
+
 // export kernels for the unit-parity entry point
 __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restrict__ d, double* __restrict__ lx,
                              double* __restrict__ lxx11, double* __restrict__ kk, double* __restrict__ K) {
@@ -1538,6 +1610,7 @@ struct tolg_handle_s {
   tolg_options run_opt;
   int run_it;         // iterations issued so far
   bool running;
+  const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -1662,6 +1735,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->ev_used = 0;
   h->running = false;
   h->run_it = 0;
+  h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
   c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
@@ -1781,6 +1855,7 @@ static Params params_for(tolg_handle_s* h, int B) {
   P.Bp = (B + 3) / 4 * 4;
   P.J_hist = P.grad_hist = P.defect_hist = P.alpha_hist = P.mu_hist = nullptr;
   P.max_iter = 0; P.tol_grad = 0; P.tol_defect = 0; P.max_reg = 1e10;
+  P.al_lb = h->al_lb; P.al_ub = h->al_ub; P.al_lambda = h->al_lambda; P.al_imu = h->al_imu;
   return P;
 }
 
@@ -1951,6 +2026,27 @@ extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_
   if (rc) return rc;
   if ((rc = tolg_solve_iterate(h, opt->max_iter, stream))) return rc;
   return tolg_solve_end(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream);
+}
+
+extern "C" int tolg_set_al(tolg_handle_t h, const double* d_lb, const double* d_ub, const double* d_lambda,
+                           const double* d_imu) {
+  if (!h || h->running) return TOLG_E_ARG;
+  if (d_lb && (!d_ub || !d_lambda || !d_imu)) return TOLG_E_ARG;
+  h->al_lb = d_lb; h->al_ub = d_lb ? d_ub : nullptr;
+  h->al_lambda = d_lb ? d_lambda : nullptr; h->al_imu = d_lb ? d_imu : nullptr;
+  return 0;
+}
+
+extern "C" int tolg_al_update(tolg_handle_t h, int32_t B, const double* d_us, const double* d_lb, const double* d_ub,
+                              double* d_lambda, double* d_imu, double* d_mu, double mu_scale, double mu_max,
+                              double tol_constr, double* d_maxviol, int32_t* d_al_converged, void* stream) {
+  if (!h || B < 1 || !d_us || !d_lb || !d_ub || !d_lambda || !d_imu || !d_mu || !d_maxviol || !d_al_converged)
+    return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_al_update, dim3((B + 63) / 64), dim3(64), 0, st, B, h->prob.N, h->prob.m, d_us, d_lb, d_ub,
+                     d_lambda, d_imu, d_mu, mu_scale, mu_max, tol_constr, d_maxviol, d_al_converged);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_reg, int32_t B, const double* d_xs_q,

@@ -179,6 +179,63 @@ class BatchedTrackingILQR:
         return self.solve_end()
 
     # ------------------------------------------------------------------------------------------
+    def set_al(self, lb=None, ub=None, lam=None, imu=None):
+        """Attach (or detach with lb=None) the augmented-Lagrangian box input constraint terms
+        (ALConstrainedCost + InputConstraint).  lam, imu: device tensors [B, N, 2m]."""
+        if lb is None:
+            self._al = None
+            rc = self.lib.tolg_set_al(self._h, None, None, None, None)
+        else:
+            lb = self._dev(lb, (self.m,)); ub = self._dev(ub, (self.m,))
+            self._al = (lb, ub, lam, imu)  # keep alive
+            rc = self.lib.tolg_set_al(self._h, _ptr(lb), _ptr(ub), _ptr(lam), _ptr(imu))
+        _capi.check(rc, "tolg_set_al")
+
+    def al_fit_batch(self, x0_q, x0_xi, us_init, lb, ub, n_al_iters=100, n_ilqr_iters=200, tol_grad_norm=1e-6,
+                     tol_d_norm=1e-6, tol_constr=1e-2, mu0=1e-2, mu_scale=10.0, mu_max=1e8, line_search=False):
+        """AL_iLQR_Tracking_SE3_MS.fit (reference traoptlibrary/traopt_controller.py:3218-3267) for B
+        independent problems: every outer iteration re-solves from (x0, us_init) -- no warm start, as in
+        the reference -- then updates multipliers on the device.  Returns (FitResult, info dict)."""
+        x0_q = self._dev(x0_q, (-1, 16))
+        B = x0_q.shape[0]
+        f64 = dict(dtype=torch.float64, device=self.device)
+        lam = torch.zeros(B, self.N, 2 * self.m, **f64)
+        imu = torch.full((B, self.N, 2 * self.m), float(mu0), **f64)
+        mu = torch.full((B,), float(mu0), **f64)
+        maxviol = torch.zeros(B, **f64)
+        alconv = torch.zeros(B, dtype=torch.int32, device=self.device)
+        lb_d = self._dev(lb, (self.m,)); ub_d = self._dev(ub, (self.m,))
+        self.set_al(lb_d, ub_d, lam, imu)
+        outer = 0
+        res = None
+        final = None
+        try:
+            for outer in range(int(n_al_iters)):
+                res = self.fit_batch(x0_q, x0_xi, us_init, mode="ms", n_iterations=n_ilqr_iters,
+                                     tol_grad_norm=tol_grad_norm, tol_d_norm=tol_d_norm, line_search=line_search,
+                                     rollout="nonlinear")
+                if final is None:
+                    final = res
+                else:  # problems that had already converged keep the result of their converging solve
+                    keep = alconv.bool()
+                    for name in ("xs_q", "xs_xi", "us", "J_hist", "grad_hist", "defect_hist", "alpha_hist",
+                                 "mu_hist", "iters", "status", "converged"):
+                        new, old = getattr(res, name), getattr(final, name)
+                        if new is not None:
+                            new[keep] = old[keep]
+                    final = res
+                with torch.cuda.device(self.device):
+                    rc = self.lib.tolg_al_update(self._h, B, _ptr(final.us), _ptr(lb_d), _ptr(ub_d), _ptr(lam), _ptr(imu),
+                                                 _ptr(mu), float(mu_scale), float(mu_max), float(tol_constr),
+                                                 _ptr(maxviol), _ptr(alconv), self._stream())
+                _capi.check(rc, "tolg_al_update")
+                if bool(alconv.all().item()):
+                    break
+        finally:
+            self.set_al(None)
+        return final, dict(lmbd=lam, Imu=imu, mu=mu, max_violation=maxviol, al_converged=alconv, outer_iterations=outer + 1)
+
+    # ------------------------------------------------------------------------------------------
     def linearize_backward(self, xs_q, xs_xi, us, ms=True, mu=1.0, delta=2.0, max_reg=1e10):
         """One _linearization + _backward_pass (+ gradient norm) on given trajectories."""
         xs_q = self._dev(xs_q, (-1, self.N + 1, 16))
