@@ -103,6 +103,10 @@ int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const 
 int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream);
 int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
                    int32_t* d_status, int32_t* d_converged, void* stream);
+/* Same export without ending the solve: what the per-iteration on_iteration callback of
+ * traoptlibrary/traopt_controller.py:2621-2626 needs (current xs, us) when a caller wants it. */
+int tolg_solve_peek(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                    int32_t* d_status, int32_t* d_converged, void* stream);
 
 /* Augmented-Lagrangian box input constraint lb <= u <= ub -- replaces ALConstrainedCost wrapping the
  * tracking cost with an InputConstraint (traoptlibrary/traopt_cost.py:1173-1320,
@@ -133,6 +137,17 @@ int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_reg, int32_t
                             const double* d_xs_xi, const double* d_us, double* d_mu_delta, double* d_Fx,
                             double* d_d, double* d_lx, double* d_lxx11, double* d_k, double* d_K,
                             double* d_J, double* d_dnorm, double* d_grad, void* stream);
+
+/* The reference's per-knot plugin methods for n states at knot i (i == N: terminal) -- replaces
+ * dynamics.f / f_x / f_u (traoptlibrary/traopt_dynamics.py:789-850, :1403-1482) and cost.l / l_x / l_u /
+ * l_xx / l_uu / _err (traoptlibrary/traopt_cost.py:659-867; with tolg_set_al active: ALConstrainedCost).
+ *   in : d_x_q [n][16], d_x_xi [n][6], d_u [n][m] (ignored at the terminal knot)
+ *   out: d_f_q [n][16], d_f_xi [n][6], d_Fx [n][12][12], d_Fu [n][12][m], d_l [n], d_lx [n][12],
+ *        d_lxx [n][12][12], d_lu [n][m], d_luu [n][m][m], d_err [n][12] = [Log(x x_ref^-1); xi - xi_ref].
+ * Any output may be NULL.  Uses the handle's workspace: not to be called during a solve in flight. */
+int tolg_eval_knot(tolg_handle_t h, int32_t i, int32_t n, const double* d_x_q, const double* d_x_xi,
+                   const double* d_u, double* d_f_q, double* d_f_xi, double* d_Fx, double* d_Fu, double* d_l,
+                   double* d_lx, double* d_lxx, double* d_lu, double* d_luu, double* d_err, void* stream);
 
 /* One closed-loop rollout with the gains left by the last tolg_linearize_backward on the same
  * trajectories -- replaces iLQR_Tracking_SE3_MS._rollout (:2641-2740) / iLQR_Tracking_SE3._rollout

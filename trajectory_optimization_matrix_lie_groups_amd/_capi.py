@@ -24,7 +24,7 @@ class Options(C.Structure):
 
 _lib = None
 SYMBOLS = ["tolg_workspace_bytes", "tolg_create", "tolg_destroy", "tolg_solve_batch", "tolg_solve_begin",
-           "tolg_solve_iterate", "tolg_solve_end", "tolg_set_al", "tolg_al_update", "tolg_linearize_backward",
+           "tolg_solve_iterate", "tolg_solve_end", "tolg_solve_peek", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
            "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version"]
 
 
@@ -55,10 +55,14 @@ def load():
     lib.tolg_solve_iterate.argtypes = [vp, C.c_int32, vp]
     lib.tolg_solve_end.restype = C.c_int
     lib.tolg_solve_end.argtypes = [vp, dp, dp, dp, ip, ip, ip, vp]
+    lib.tolg_solve_peek.restype = C.c_int
+    lib.tolg_solve_peek.argtypes = [vp, dp, dp, dp, ip, ip, ip, vp]
     lib.tolg_set_al.restype = C.c_int
     lib.tolg_set_al.argtypes = [vp, dp, dp, dp, dp]
     lib.tolg_al_update.restype = C.c_int
     lib.tolg_al_update.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, ip, vp]
+    lib.tolg_eval_knot.restype = C.c_int
+    lib.tolg_eval_knot.argtypes = [vp, C.c_int32, C.c_int32] + [dp] * 13 + [vp]
     lib.tolg_linearize_backward.restype = C.c_int
     lib.tolg_linearize_backward.argtypes = [vp, C.c_int32, C.c_double, C.c_int32] + [dp] * 13 + [vp]
     lib.tolg_rollout.restype = C.c_int

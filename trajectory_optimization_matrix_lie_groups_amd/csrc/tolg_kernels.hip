@@ -320,11 +320,13 @@ __global__ void k_init_rollout(Params P) {
 template <int M>
 __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
                                                     const double* __restrict__ src_u, double* __restrict__ dst,
-                                                    double* __restrict__ dst_u, int ms) {
+                                                    double* __restrict__ dst_u, int ms, int i0, int ni) {
+  // ms: 1 multiple shooting, 0 single shooting, 2 probe (tolg_eval_knot: f(x,u) goes to REC_M/REC_C,
+  // the tracking error to REC_D, nothing is read from knot i+1); knots [i0, i0 + ni)
   const Consts& C = *P.c;
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)(P.N + 1) * P.Bp) return;
-  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  if (t >= (size_t)ni * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
   if (!P.active[b]) return;
   const bool term = (i == P.N);
   const double dt = C.dt;
@@ -376,6 +378,10 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         Je[6 * (a + 3) + c] = Jb[3 * a + c];
         Je[6 * (a + 3) + c + 3] = Ja[3 * a + c];
       }
+    if (ms == 2) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) { P.REC[RIDX(i, REC_D + a, b)] = e[a]; P.REC[RIDX(i, REC_D + 6 + a, b)] = ve[a]; }
+    }
     double We[6], W2v[6], l = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
@@ -517,6 +523,15 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   double d[12];
   Pose Mx;
   V3 cw, cv;
+  if (ms == 2) {  // probe: export f(x, u) itself
+    State F = dyn_f<M>(C, S, u);
+    P.REC[RIDX(i, REC_M + 0, b)] = F.X.q.x; P.REC[RIDX(i, REC_M + 1, b)] = F.X.q.y;
+    P.REC[RIDX(i, REC_M + 2, b)] = F.X.q.z; P.REC[RIDX(i, REC_M + 3, b)] = F.X.q.w;
+    P.REC[RIDX(i, REC_M + 4, b)] = F.X.t.x; P.REC[RIDX(i, REC_M + 5, b)] = F.X.t.y; P.REC[RIDX(i, REC_M + 6, b)] = F.X.t.z;
+    P.REC[RIDX(i, REC_C + 0, b)] = F.w.x; P.REC[RIDX(i, REC_C + 1, b)] = F.w.y; P.REC[RIDX(i, REC_C + 2, b)] = F.w.z;
+    P.REC[RIDX(i, REC_C + 3, b)] = F.v.x; P.REC[RIDX(i, REC_C + 4, b)] = F.v.y; P.REC[RIDX(i, REC_C + 5, b)] = F.v.z;
+    return;
+  }
   if (ms) {
     State F = dyn_f<M>(C, S, u);
     State Sn = load_state(P, src, i + 1, b);
@@ -1538,6 +1553,89 @@ __global__ void k_al_update(int B, int N, int m, const double* __restrict__ us, 
   mu[b] = mu_new;
 }
 
+// ---- single-knot probe (tolg_eval_knot): the reference's per-knot plugin methods f, f_x, f_u, l, l_x,
+// l_u, l_xx, l_uu, _err evaluated for n states at knot i
+__global__ void k_probe_pack(Params P, int i, const double* __restrict__ x_q, const double* __restrict__ x_xi,
+                             const double* __restrict__ u) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp) return;
+  int bs = b < P.B ? b : P.B - 1;
+  State S;
+  S.X = pose_from_m16(x_q + 16 * (size_t)bs);
+  const double* x = x_xi + 6 * (size_t)bs;
+  S.w = v3(x[0], x[1], x[2]);
+  S.v = v3(x[3], x[4], x[5]);
+  store_state(P, P.cur, i, b, S);
+  if (i < P.N)
+    for (int a = 0; a < P.m; a++) P.cur_u[UIDX(a, i, b)] = u ? u[(size_t)bs * P.m + a] : 0.0;
+  P.active[b] = 1;
+}
+__global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double* __restrict__ f_xi,
+                               double* __restrict__ Fx, double* __restrict__ Fu, double* __restrict__ l,
+                               double* __restrict__ lx, double* __restrict__ lxx, double* __restrict__ lu,
+                               double* __restrict__ luu, double* __restrict__ err) {
+  const Consts& C = *P.c;
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  const bool term = (i == P.N);
+  const int m = P.m;
+  if (l) l[b] = P.SC[(size_t)i * P.Bp + b];
+  if (lx) for (int r = 0; r < 12; r++) lx[(size_t)b * 12 + r] = P.REC[RIDX(i, REC_LX + r, b)];
+  if (lxx) {
+    const double* W2 = term ? C.P2 : C.W2;
+    double* L = lxx + (size_t)b * 144;
+    for (int k = 0; k < 144; k++) L[k] = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        L[12 * r + c] = P.REC[RIDX(i, REC_LXX + sym6(r, c), b)];
+        L[12 * (r + 6) + c + 6] = 2.0 * W2[6 * r + c];
+      }
+  }
+  if (err) for (int r = 0; r < 12; r++) err[(size_t)b * 12 + r] = P.REC[RIDX(i, REC_D + r, b)];
+  if (term) return;
+  if (lu) for (int a = 0; a < m; a++) lu[(size_t)b * m + a] = P.REC[RIDX(i, REC_LU + a, b)];
+  if (luu)
+    for (int a = 0; a < m; a++)
+      for (int k = 0; k < m; k++)
+        luu[((size_t)b * m + a) * m + k] = 2.0 * C.R[a * m + k] + (a == k ? P.REC[RIDX(i, REC_LUU + a, b)] : 0.0);
+  if (f_q) {
+    Pose X;
+    X.q.x = P.REC[RIDX(i, REC_M + 0, b)]; X.q.y = P.REC[RIDX(i, REC_M + 1, b)];
+    X.q.z = P.REC[RIDX(i, REC_M + 2, b)]; X.q.w = P.REC[RIDX(i, REC_M + 3, b)];
+    X.t = v3(P.REC[RIDX(i, REC_M + 4, b)], P.REC[RIDX(i, REC_M + 5, b)], P.REC[RIDX(i, REC_M + 6, b)]);
+    pose_to_m16(X, f_q + 16 * (size_t)b);
+  }
+  if (f_xi) for (int a = 0; a < 6; a++) f_xi[(size_t)b * 6 + a] = P.REC[RIDX(i, REC_C + a, b)];
+  if (Fu) {
+    double* F = Fu + (size_t)b * 12 * m;
+    for (int k = 0; k < 12 * m; k++) F[k] = 0;
+    for (int r = 0; r < 6; r++)
+      for (int k = 0; k < m; k++)
+        F[(6 + r) * m + k] = (r < 3) ? (k < 3 ? C.Bt[3 * r + k] : 0.0) : (k >= 3 ? C.Bb[3 * (r - 3) + (k - 3)] : 0.0);
+  }
+  if (Fx) {
+    double* F = Fx + (size_t)b * 144;
+    for (int k = 0; k < 144; k++) F[k] = 0;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double ri = P.REC[RIDX(i, REC_RI + 3 * c + r, b)], jr = P.REC[RIDX(i, REC_JR + 3 * c + r, b)];
+        F[12 * r + c] = ri; F[12 * (r + 3) + c + 3] = ri;
+        F[12 * (r + 3) + c] = P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
+        F[12 * r + c + 6] = jr; F[12 * (r + 3) + c + 9] = jr;
+        F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
+      }
+    double rte[3];
+    for (int a = 0; a < 3; a++) rte[a] = P.REC[RIDX(i, REC_RTE + a, b)];
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        double lsum = 0;
+        for (int a = 0; a < 3; a++) lsum += rte[a] * C.Llin[a][6 * r + c];
+        F[12 * (r + 6) + c + 6] = P.REC[RIDX(i, REC_A22 + 6 * c + r, b)];
+        F[12 * (r + 6) + c] = lsum;
+      }
+  }
+}
+
 // export kernels for the unit-parity entry point
 __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restrict__ d, double* __restrict__ lx,
                              double* __restrict__ lxx11, double* __restrict__ kk, double* __restrict__ K) {
@@ -1861,10 +1959,12 @@ static Params params_for(tolg_handle_s* h, int B) {
 
 template <int M>
 static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, const double* src, const double* src_u,
-                         double* dst, double* dst_u, int ms) {
-  size_t n = (size_t)(P.N + 1) * P.Bp;
+                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1) {
+  if (ni < 0) ni = P.N + 1;
+  size_t n = (size_t)ni * P.Bp;
   Timed t(h, st, 2);
-  hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms);
+  hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms,
+                     i0, ni);
   LAUNCH_CHECK();
   return 0;
 }
@@ -2000,8 +2100,8 @@ extern "C" int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream)
   return 0;
 }
 
-extern "C" int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
-                              int32_t* d_status, int32_t* d_converged, void* stream) {
+static int solve_export(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                        int32_t* d_status, int32_t* d_converged, void* stream, bool end) {
   if (!h || !h->running) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Params& P = h->run;
@@ -2012,8 +2112,16 @@ extern "C" int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, 
   hipLaunchKernelGGL(k_export_scalars, dim3((P.B + 63) / 64), dim3(64), 0, st, P, nullptr, nullptr, nullptr, nullptr,
                      d_iters, d_status, d_converged);
   LAUNCH_CHECK();
-  h->running = false;
+  if (end) h->running = false;
   return 0;
+}
+extern "C" int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                              int32_t* d_status, int32_t* d_converged, void* stream) {
+  return solve_export(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream, true);
+}
+extern "C" int tolg_solve_peek(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
+                               int32_t* d_status, int32_t* d_converged, void* stream) {
+  return solve_export(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream, false);
 }
 
 extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
@@ -2076,6 +2184,25 @@ extern "C" int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_r
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_export_scalars, dim3((B + 63) / 64), dim3(64), 0, st, P, d_J, d_dnorm, d_grad, d_mu_delta,
                      nullptr, nullptr, nullptr);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tolg_eval_knot(tolg_handle_t h, int32_t i, int32_t n, const double* d_x_q, const double* d_x_xi,
+                              const double* d_u, double* d_f_q, double* d_f_xi, double* d_Fx, double* d_Fu,
+                              double* d_l, double* d_lx, double* d_lxx, double* d_lu, double* d_luu, double* d_err,
+                              void* stream) {
+  if (!h || h->running || n < 1 || n > h->max_batch || i < 0 || i > h->prob.N || !d_x_q || !d_x_xi) return TOLG_E_ARG;
+  if (i < h->prob.N && !d_u) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Params P = params_for(h, n);
+  hipLaunchKernelGGL(k_probe_pack, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, i, d_x_q, d_x_xi, d_u);
+  LAUNCH_CHECK();
+  int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 2, i, 1)
+                      : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, 2, i, 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_probe_export, dim3((n + 63) / 64), dim3(64), 0, st, P, i, d_f_q, d_f_xi, d_Fx, d_Fu, d_l, d_lx,
+                     d_lxx, d_lu, d_luu, d_err);
   LAUNCH_CHECK();
   return 0;
 }

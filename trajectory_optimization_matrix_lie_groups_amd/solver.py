@@ -160,6 +160,15 @@ class BatchedTrackingILQR:
             rc = self.lib.tolg_solve_iterate(self._h, int(n_iter), self._stream())
         _capi.check(rc, "tolg_solve_iterate")
 
+    def solve_peek(self) -> FitResult:
+        """Export the trajectories in flight (xs, us, iters, status) without ending the solve."""
+        out = self._inflight[0]
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_peek(self._h, _ptr(out.xs_q), _ptr(out.xs_xi), _ptr(out.us), _ptr(out.iters),
+                                          _ptr(out.status), _ptr(out.converged), self._stream())
+        _capi.check(rc, "tolg_solve_peek")
+        return out
+
     def solve_end(self) -> FitResult:
         out = self._inflight[0]
         with torch.cuda.device(self.device):
@@ -192,7 +201,8 @@ class BatchedTrackingILQR:
         _capi.check(rc, "tolg_set_al")
 
     def al_fit_batch(self, x0_q, x0_xi, us_init, lb, ub, n_al_iters=100, n_ilqr_iters=200, tol_grad_norm=1e-6,
-                     tol_d_norm=1e-6, tol_constr=1e-2, mu0=1e-2, mu_scale=10.0, mu_max=1e8, line_search=False):
+                     tol_d_norm=1e-6, tol_constr=1e-2, mu0=1e-2, mu_scale=10.0, mu_max=1e8, line_search=False,
+                     on_outer=None):
         """AL_iLQR_Tracking_SE3_MS.fit (reference traoptlibrary/traopt_controller.py:3218-3267) for B
         independent problems: every outer iteration re-solves from (x0, us_init) -- no warm start, as in
         the reference -- then updates multipliers on the device.  Returns (FitResult, info dict)."""
@@ -224,6 +234,8 @@ class BatchedTrackingILQR:
                         if new is not None:
                             new[keep] = old[keep]
                     final = res
+                if on_outer is not None:  # before the multiplier update, like on_iteration_al (:3253-3259)
+                    on_outer(outer, final, lam, imu, mu)
                 with torch.cuda.device(self.device):
                     rc = self.lib.tolg_al_update(self._h, B, _ptr(final.us), _ptr(lb_d), _ptr(ub_d), _ptr(lam), _ptr(imu),
                                                  _ptr(mu), float(mu_scale), float(mu_max), float(tol_constr),
@@ -256,6 +268,28 @@ class BatchedTrackingILQR:
                                                   _ptr(r["k"]), _ptr(r["K"]), _ptr(r["J"]), _ptr(r["dnorm"]),
                                                   _ptr(r["grad"]), self._stream())
         _capi.check(rc, "tolg_linearize_backward")
+        return r
+
+    def eval_knot(self, i, x_q, x_xi, u=None):
+        """Per-knot plugin quantities (f, f_x, f_u, l, l_x, l_xx, l_u, l_uu, err) for n states at knot i."""
+        x_q = self._dev(x_q, (-1, 16))
+        n = x_q.shape[0]
+        x_xi = self._dev(x_xi, (n, 6))
+        term = int(i) == self.N
+        u_d = None if (u is None or term) else self._dev(u, (n, self.m))
+        f64 = dict(dtype=torch.float64, device=self.device)
+        r = dict(l=torch.zeros(n, **f64), lx=torch.zeros(n, 12, **f64), lxx=torch.zeros(n, 12, 12, **f64),
+                 err=torch.zeros(n, 12, **f64))
+        if not term:
+            r.update(f_q=torch.zeros(n, 4, 4, **f64), f_xi=torch.zeros(n, 6, **f64), Fx=torch.zeros(n, 12, 12, **f64),
+                     Fu=torch.zeros(n, 12, self.m, **f64), lu=torch.zeros(n, self.m, **f64),
+                     luu=torch.zeros(n, self.m, self.m, **f64))
+        g = lambda k: _ptr(r.get(k))  # noqa: E731
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_eval_knot(self._h, int(i), n, _ptr(x_q), _ptr(x_xi), _ptr(u_d), g("f_q"), g("f_xi"),
+                                         g("Fx"), g("Fu"), g("l"), g("lx"), g("lxx"), g("lu"), g("luu"), g("err"),
+                                         self._stream())
+        _capi.check(rc, "tolg_eval_knot")
         return r
 
     def rollout(self, B, alpha=1.0, ms=True, rollout="nonlinear"):

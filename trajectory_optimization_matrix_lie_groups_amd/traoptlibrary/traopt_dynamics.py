@@ -1,0 +1,157 @@
+"""Dynamics plugins with the reference's interface (traoptlibrary/traopt_dynamics.py).
+
+BaseDynamics :14-130, SE3Dynamics :629-898, RigidBodyDynamics :901-1206, DroneDynamics :1209-1530.
+The per-knot methods evaluate on the GPU through tolg_eval_knot; the controllers never call them in
+their loops (they hand the whole problem to the fused kernels)."""
+import abc
+
+import numpy as np
+
+from . import _bridge
+
+
+class BaseDynamics():
+    """Dynamics Model (traopt_dynamics.py:14-130)."""
+
+    @property
+    @abc.abstractmethod
+    def state_size(self):
+        raise NotImplementedError
+
+    @property
+    @abc.abstractmethod
+    def action_size(self):
+        raise NotImplementedError
+
+    @property
+    @abc.abstractmethod
+    def has_hessians(self):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f(self, x, u, i):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f_x(self, x, u, i):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f_u(self, x, u, i):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f_xx(self, x, u, i):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f_ux(self, x, u, i):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def f_uu(self, x, u, i):
+        raise NotImplementedError
+
+
+class _RigidBodyOnSE3(BaseDynamics):
+    _kind = "se3"
+
+    def __init__(self, J, dt, integration_method="euler", state_size=(6, 6), action_size=6, hessians=False,
+                 debug=None, **kwargs):
+        self._state_size = state_size[0] + state_size[1]
+        self._error_state_size = state_size[0]
+        self._vel_state_size = state_size[1]
+        self._action_size = action_size
+        J = np.asarray(J, dtype=float)
+        self._Ib = J[0:3, 0:3]
+        self._m = J[4, 4]
+        self._J = J
+        self._Jinv = np.linalg.inv(J)
+        self._dt = dt
+        self._integration_method = integration_method
+        if integration_method == "euler":
+            pass
+        elif integration_method == "rk4":
+            raise ValueError("RK4 not implemented yet.")  # traopt_dynamics.py:676-678
+        else:
+            raise ValueError("Invalid integration method. Choose 'euler' or 'rk4'.")
+        self._has_hessians = hessians
+        self._debug = debug
+        self._probe_solver = None
+
+    state_size = property(lambda self: self._state_size)
+    error_state_size = property(lambda self: self._error_state_size)
+    vel_state_size = property(lambda self: self._vel_state_size)
+    action_size = property(lambda self: self._action_size)
+    has_hessians = property(lambda self: self._has_hessians)
+    Ib = property(lambda self: self._Ib)
+    m = property(lambda self: self._m)
+    J = property(lambda self: self._J)
+    Jinv = property(lambda self: self._Jinv)
+    dt = property(lambda self: self._dt)
+
+    def _probe(self):
+        if self._probe_solver is None:
+            self._probe_solver = _bridge.dynamics_probe(self._kind, self._J, self._dt)
+        return self._probe_solver
+
+    def _eval(self, x, u):
+        q, xi = _bridge.split_state(x)
+        return self._probe().eval_knot(0, q, xi, np.asarray(u, float).reshape(1, self._action_size))
+
+    def f(self, x, u, i):
+        """Next state [q (4,4), xi (6,)] (traopt_dynamics.py:763-800)."""
+        r = self._eval(x, u)
+        return [_bridge.host(r["f_q"])[0], _bridge.host(r["f_xi"])[0]]
+
+    def fd_euler(self, x, u, i):
+        return self.f(x, u, i)
+
+    def f_x(self, x, u, i):
+        """df/dx [12, 12] (traopt_dynamics.py:802-837), the reference's literal Jacobian."""
+        return _bridge.host(self._eval(x, u)["Fx"])[0]
+
+    def f_u(self, x, u, i):
+        """df/du [12, m] (traopt_dynamics.py:839-850)."""
+        return _bridge.host(self._eval(x, u)["Fu"])[0]
+
+    def f_xx(self, x, u, i):
+        raise NotImplementedError  # traopt_dynamics.py:863-866: never available for the exact models
+
+    def f_ux(self, x, u, i):
+        raise NotImplementedError
+
+    def f_uu(self, x, u, i):
+        raise NotImplementedError
+
+
+class SE3Dynamics(_RigidBodyOnSE3):
+    """Error-State SE(3) Dynamics Model (traopt_dynamics.py:629-898)."""
+    _kind = "se3"
+
+
+class RigidBodyDynamics(_RigidBodyOnSE3):
+    """SE(3) Dynamics with Gravity (traopt_dynamics.py:901-1206)."""
+    _kind = "rigidbody"
+
+    def __init__(self, J, dt, integration_method="euler", state_size=(6, 6), action_size=6, hessians=False,
+                 debug=None, **kwargs):
+        super().__init__(J, dt, integration_method, state_size, action_size, hessians, debug, **kwargs)
+        self._g = 9.8
+
+    g = property(lambda self: self._g)
+
+
+class DroneDynamics(_RigidBodyOnSE3):
+    """Drone Dynamics: SE(3) dynamics with gravity and the 4 -> 6 input map (traopt_dynamics.py:1209-1530)."""
+    _kind = "drone"
+
+    def __init__(self, J, dt, integration_method="euler", state_size=(6, 6), action_size=4, hessians=False,
+                 debug=None, **kwargs):
+        super().__init__(J, dt, integration_method, state_size, action_size, hessians, debug, **kwargs)
+        self._g = 9.8
+        self._Pu = np.zeros((6, 4))
+        self._Pu[0, 0] = self._Pu[1, 1] = self._Pu[2, 2] = self._Pu[5, 3] = 1.0
+
+    g = property(lambda self: self._g)
+    Pu = property(lambda self: self._Pu)
