@@ -25,7 +25,13 @@
 extern "C" {
 #endif
 
-enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2 };
+/* TOLG_DYN_SO3: SO3Dynamics / SO3TrackingQuadraticGaussNewtonCost / iLQR_Tracking_SO3{,_MS}
+ * (traoptlibrary/traopt_dynamics.py:275-418, traopt_cost.py:280-564, traopt_controller.py:526-1824)
+ * carried in the SE(3) layout: poses are 4x4 with zero translation, twists [omega, 0], m = 6 with
+ * u[3:6] = 0, J = blkdiag(J_so3, I3), R = blkdiag(R_so3, I3), Q/P with zero rows for the unused
+ * coordinates.  The rotational sub-problem decouples exactly; Jacobian and cost follow the SO3
+ * classes (no swapped-twist quirk, terminal l and l_x weighted with Q). */
+enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3 };
 enum { TOLG_MODE_MS = 0, TOLG_MODE_SS = 1 };
 enum { TOLG_E_ARG = -1, TOLG_E_WORKSPACE = -2, TOLG_E_LAUNCH = -3, TOLG_E_SINGULAR = -4 };
 enum { TOLG_ST_OK = 0, TOLG_ST_MAXREG = 1, TOLG_ST_NODESCENT = 2, TOLG_ST_NONFINITE = 3 };

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtolg_oracle.so")
 
-DYN_SE3, DYN_RIGIDBODY, DYN_DRONE = 0, 1, 2
+DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3 = 0, 1, 2, 3
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -68,7 +68,7 @@ class OracleProblem:
     """Holds a Problem struct plus the numpy arrays it points into."""
 
     def __init__(self, kind, J, dt, Q, R, P, q_ref, xi_ref, al=None):
-        kind = {"se3": DYN_SE3, "rigidbody": DYN_RIGIDBODY, "drone": DYN_DRONE}.get(kind, kind)
+        kind = {"se3": DYN_SE3, "rigidbody": DYN_RIGIDBODY, "drone": DYN_DRONE, "so3": DYN_SO3}.get(kind, kind)
         self.m = 4 if kind == DYN_DRONE else 6
         self.N = int(q_ref.shape[0]) - 1
         self.q_ref = _c(q_ref, (self.N + 1, 16))
@@ -197,3 +197,21 @@ def cost(prob, q, xi, u, i, terminal=False):
     lib().tolg_oracle_cost(C.byref(prob.c), _p(q), _p(xi), _p(u), int(i), int(terminal), C.byref(l), _p(lx), _p(lxx),
                            _p(lu), _p(luu))
     return l.value, lx, lxx, lu, luu
+
+
+def embed_so3_problem(J3, dt, Q6, R3, P6, R_ref, w_ref):
+    """SO(3) tracking problem in the SE(3) containers (see tolg_oracle.c, TOLG_DYN_SO3): translation,
+    linear velocity and inputs 3..5 are identically zero."""
+    n = R_ref.shape[0]
+    J = np.eye(6); J[:3, :3] = J3
+    Q = np.zeros((12, 12)); Q[:3, :3] = Q6[:3, :3]; Q[6:9, 6:9] = Q6[3:, 3:]
+    P = np.zeros((12, 12)); P[:3, :3] = P6[:3, :3]; P[6:9, 6:9] = P6[3:, 3:]
+    R = np.eye(6); R[:3, :3] = R3
+    q_ref = np.tile(np.eye(4), (n, 1, 1)); q_ref[:, :3, :3] = R_ref
+    xi_ref = np.zeros((n, 6)); xi_ref[:, :3] = w_ref
+    return OracleProblem("so3", J, dt, Q, R, P, q_ref, xi_ref)
+
+
+def embed_so3_state(R0, w0):
+    q = np.eye(4); q[:3, :3] = R0
+    return q, np.r_[np.asarray(w0, float).reshape(3), 0, 0, 0]

@@ -337,7 +337,12 @@ static void coad6(const double xi[6], double A[36]) {
 /* ------------------------------------------------------------------------------------------ */
 /* problem description                                                                         */
 /* ------------------------------------------------------------------------------------------ */
-enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2 };
+/* TOLG_DYN_SO3: SO3Dynamics + SO3TrackingQuadraticGaussNewtonCost + iLQR_Tracking_SO3{,_MS} carried in the
+ * SE(3) containers with translation, linear velocity and the last three inputs identically zero
+ * (J = blkdiag(J_so3, I3)): the rotational sub-problem decouples exactly, so costs, gradients, defects
+ * and iterates are those of the SO(3) solver.  Pinned against the reference's SO3 run in
+ * tests/golden/so3_n249_log.json. */
+enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3 };
 
 typedef struct {
   int kind;          /* SE3Dynamics / RigidBodyDynamics / DroneDynamics */
@@ -391,7 +396,7 @@ static int dyn_init(const tolg_problem *p, dyn_cache *c) {
   if (inv6(p->J, c->Jinv)) return -1;
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c->Ib[3 * i + j] = p->J[6 * i + j];
   c->mass = p->J[6 * 4 + 4];
-  c->grav = (p->kind == TOLG_DYN_SE3) ? 0.0 : 9.8;
+  c->grav = (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;
   memset(c->Pu, 0, sizeof c->Pu);
   if (p->kind == TOLG_DYN_DRONE) {
     if (m != 4) return -2;
@@ -459,10 +464,25 @@ static void dyn_fx(const tolg_problem *p, const dyn_cache *c, const double q[16]
     }
   double sw[6] = {xi[3], xi[4], xi[5], xi[0], xi[1], xi[2]}; /* manif coeffs [v, w] */
   double co[36], coJ[36], H[36];
-  coad6(sw, co);
-  mm(6, 6, 6, co, p->J, coJ);
-  for (int i = 0; i < 36; i++) coJ[i] += G[i];
-  mm(6, 6, 6, c->Jinv, coJ, H);
+  if (p->kind == TOLG_DYN_SO3) {
+    /* SO3Dynamics.f_x (traopt_dynamics.py:385-400): G = skew(J w), H = J^-1 (smallAdj(w)^T J + G) with
+     * smallAdj(w) = skew(w) -- no swapped-twist quirk on SO(3); the unused v block stays the identity */
+    double Sw[9], JJ[9], Ji3[9], T3[9], H3[9];
+    skew3(xi, Sw);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { JJ[3 * i + j] = p->J[6 * i + j]; Ji3[3 * i + j] = c->Jinv[6 * i + j]; }
+    double SwT[9];
+    mat3_T(Sw, SwT);
+    mat3_mul(SwT, JJ, T3);
+    for (int i = 0; i < 9; i++) T3[i] += SIw[i];
+    mat3_mul(Ji3, T3, H3);
+    memset(H, 0, sizeof H);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H[6 * i + j] = H3[3 * i + j];
+  } else {
+    coad6(sw, co);
+    mm(6, 6, 6, co, p->J, coJ);
+    for (int i = 0; i < 36; i++) coJ[i] += G[i];
+    mm(6, 6, 6, c->Jinv, coJ, H);
+  }
   double L[36];
   memset(L, 0, sizeof L);
   if (c->grav != 0.0) { /* J_v_R = skew(R^T (0,0,-1)) */
@@ -511,7 +531,8 @@ static double cost_l(const tolg_problem *p, const dyn_cache *c, const double q[1
                      const double *u, int i, int terminal) {
   se3_t X;
   double e[6], ve[6], s = 0;
-  const double *W = terminal ? p->P : p->Q;
+  /* SO3 cost: _l_terminal weighs with Q, not P (traopt_cost.py:434-438) */
+  const double *W = (terminal && p->kind != TOLG_DYN_SO3) ? p->P : p->Q;
   se3_from_matrix(q, &X);
   se3_lminus(&X, &c->qref[i], e, NULL);
   for (int a = 0; a < 6; a++) ve[a] = xi[a] - p->xi_ref[6 * i + a];
@@ -532,9 +553,11 @@ static void cost_lx_lxx(const tolg_problem *p, const dyn_cache *c, const double 
   se3_t X;
   double e[6], Je[36], W1[36], WJ[36], We[6];
   const double *W = terminal ? p->P : p->Q;
+  /* SO3 cost: l_x always uses Q (traopt_cost.py:480-483), only l_xx switches to P (:530-531) */
+  const double *Wg = (p->kind == TOLG_DYN_SO3) ? p->Q : W;
   se3_from_matrix(q, &X);
   se3_lminus(&X, &c->qref[i], e, Je);
-  for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) W1[6 * a + b] = W[12 * a + b];
+  for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) W1[6 * a + b] = Wg[12 * a + b];
   mm(6, 6, 1, W1, e, We);
   for (int a = 0; a < 6; a++) {
     double s = 0;
@@ -543,9 +566,10 @@ static void cost_lx_lxx(const tolg_problem *p, const dyn_cache *c, const double 
   }
   for (int a = 0; a < 6; a++) {
     double s = 0;
-    for (int b = 0; b < 6; b++) s += 2 * W[12 * (a + 6) + b + 6] * (xi[b] - p->xi_ref[6 * i + b]);
+    for (int b = 0; b < 6; b++) s += 2 * Wg[12 * (a + 6) + b + 6] * (xi[b] - p->xi_ref[6 * i + b]);
     lx[a + 6] = s;
   }
+  for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) W1[6 * a + b] = W[12 * a + b];
   mm(6, 6, 6, W1, Je, WJ);
   memset(lxx, 0, 144 * sizeof(double));
   for (int a = 0; a < 6; a++)
@@ -977,11 +1001,11 @@ int tolg_oracle_ms_fit(const tolg_problem *p, const tolg_options *o, const doubl
       rollout_ms(p, &c, &w, 1.0, 1); /* rollout="linear" (:2550) */
       expected_cost_change(p, &w, ecc);
       double d_weight;
-      if (dn < 1e-12) d_weight = d_weight_prev; /* _defect_kappa (:2777) */
+      if (dn < ((p->kind == TOLG_DYN_SO3) ? 1e-14 : 1e-12)) d_weight = d_weight_prev; /* _defect_kappa (:2777, SO3 :1090) */
       else d_weight = fmax(10.0, 10.0 + fabs(ecc[0] + 0.5 * ecc[1]) / ((1 - 0.5) * dn));
       d_weight_prev = d_weight;
       double merit = J_opt + d_weight * dn;
-      for (int a = 0; a < MS_ALPHAS; a++) {
+      for (int a = 0; a < ((p->kind == TOLG_DYN_SO3) ? SS_ALPHAS : MS_ALPHAS); a++) { /* SO3 MS: 13 alphas (:1160) */
         alpha = pow(1.1, -(double)(a * a));
         rollout_ms(p, &c, &w, alpha, o->rollout_linear);
         J_new = traj_cost(p, &c, w.nq, w.nxi, w.nus);

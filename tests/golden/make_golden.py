@@ -112,6 +112,77 @@ def parse_ss(lines):
     return {"iterations": [it[k] for k in range(n)], "converged": it.get("converged")}
 
 
+def parse_ms_linesearch(lines):
+    """MS prints with line_search=True (traopt_controller.py:1230-1300 for SO3): adds the nominal merit,
+    the defect weight and one 'Alpha/Cost/Merit' line per trial rollout."""
+    it = {}
+    cur = None
+    for ln in lines:
+        m = re.match(r"Iteration: (\d+) Linearization Finished, Used Time: \S+ Cost: %s DefectNorm: %s" % (FLOAT, FLOAT), ln)
+        if m:
+            cur = int(m.group(1))
+            it[cur] = {"J_lin": float(m.group(2)), "defect_lin": float(m.group(3)), "trials": []}
+            continue
+        m = re.match(r"Iteration: (\d+) Gradient w.r.t. input: %s" % FLOAT, ln)
+        if m:
+            it[int(m.group(1))]["grad"] = float(m.group(2))
+            continue
+        m = re.match(r"Iteration: (\d+) Nominal, Cost: %s Merit: %s d_weight: %s" % (FLOAT, FLOAT, FLOAT), ln)
+        if m:
+            it[int(m.group(1))]["merit"] = float(m.group(3))
+            it[int(m.group(1))]["d_weight"] = float(m.group(4))
+            continue
+        m = re.match(r"\s+Alpha: %s Cost: %s Merit: %s" % (FLOAT, FLOAT, FLOAT), ln)
+        if m and cur is not None:
+            it[cur]["trials"].append([float(m.group(1)), float(m.group(2)), float(m.group(3))])
+            continue
+        m = re.match(r"Iteration (\d+) (accepted|failed|converged) %s %s %s %s %s$" % ((FLOAT,) * 5), ln)
+        if m:
+            d = it[int(m.group(1))]
+            d["status"] = m.group(2)
+            d["cb_J"], d["cb_defect"], d["cb_grad"], d["cb_alpha"], d["cb_mu"] = [float(m.group(i)) for i in range(3, 8)]
+            continue
+        m = re.match(r"Iteration (-?\d+) converged, gradient w.r.t. input: %s" % FLOAT, ln)
+        if m:
+            it["converged"] = {"printed_iter": int(m.group(1)), "grad": float(m.group(2))}
+    n = max(k for k in it if isinstance(k, int)) + 1
+    return {"iterations": [it[k] for k in range(n)], "converged": it.get("converged")}
+
+
+def so3_notebook():
+    """baseline_SO3.ipynb cell 28: SO3Dynamics, N=249, MS with line_search=True, then SS."""
+    text = cell_stdout(os.path.join(REF, "baseline_SO3.ipynb"), 28)
+    lines = text.splitlines()
+    split = next(i for i, ln in enumerate(lines) if re.match(r"Iteration -?\d+ converged", ln)) + 1
+    end = next((i for i, ln in enumerate(lines) if "This is Ipopt" in ln), len(lines))
+    ms = parse_ms_linesearch(lines[:split])
+    ss = parse_ss(lines[split:end])
+    q_ref, xi_ref, dt = load_traj("path_3dpendulum_8shape_tryout.npy")
+    N = q_ref.shape[0] - 1
+    quat = Rotation.from_euler("zxy", [90.0, 10.0, 45.0], degrees=True).as_quat()
+    R0 = Rotation.from_quat(quat).as_matrix()
+    xi0 = np.ones(3) * 1e-1
+    J = np.diag([0.5, 0.7, 0.9])
+    Q = np.diag([10.0, 10.0, 10.0, 1.0, 1.0, 1.0])
+    # The cell SOURCE says P = 10 Q, but its stored OUTPUT is reproduced (every J, gradient, merit and
+    # d_weight of the 15 MS iterations; all 100 SS iterations) only with terminal weights equal to Q --
+    # P = Q at run time, the source being edited afterwards.  With P = 10 Q the very first recorded
+    # gradient is off by 0.5 % (MS) and the first SS cost by 9 %.  P is the one inferred quantity of
+    # this fixture (tests/test_oracle_golden.py keeps the negative control).  Consequence: this run
+    # cannot tell the HEAD quirk "l/l_x use Q, l_xx uses P at the terminal knot" (SURVEY App. C-Q3)
+    # from a consistent cost; that quirk stays restated from source, unpinned.
+    np.savez(os.path.join(OUT, "so3_n249_problem.npz"), q_ref=q_ref, xi_ref=xi_ref, dt=float(dt), q0=R0, xi0=xi0,
+             J=J, Q=Q, P=Q.copy(), R=np.identity(3) * 1e-5, us_init=np.zeros((N, 3)))
+    meta = {
+        "source": "baseline_SO3.ipynb cell 28 stdout (reference's own prints)",
+        "dynamics": "SO3Dynamics", "N": N, "action_size": 3, "tol_grad_norm": 1e-12, "max_iterations": 100,
+        "ms": {"line_search": True, "rollout": "nonlinear", **ms},
+        "ss": {"rollout": "nonlinear", **ss},
+    }
+    json.dump(meta, open(os.path.join(OUT, "so3_n249_log.json"), "w"), indent=1)
+    print("so3: MS iterations", len(ms["iterations"]), "SS iterations", len(ss["iterations"]))
+
+
 def drone_notebook():
     """baseline_applications.ipynb cell 0: DroneDynamics, N=150, MS then SS."""
     text = cell_stdout(os.path.join(REF, "baseline_applications.ipynb"), 0)
@@ -179,4 +250,5 @@ def reference_trajectories():
 
 if __name__ == "__main__":
     drone_notebook()
+    so3_notebook()
     reference_trajectories()

@@ -154,3 +154,57 @@ def test_al_controller_runs_and_enforces_box():
     assert al.l(x, u, 0) == pytest.approx(cost.l(x, u, 0) + 0.5 * g.sum() + 0.5 * 2.0 * (g @ g), rel=1e-12)
     np.testing.assert_allclose(al.l_u(x, u, 0), cost.l_u(x, u, 0) + con.g_u(x, u, 0).T @ (0.5 + 2.0 * g), rtol=1e-12)
     np.testing.assert_allclose(al.l_uu(x, u, 0), cost.l_uu(x, u, 0) + 4.0 * np.eye(6), rtol=1e-12)
+
+
+def test_so3_mirror_classes_reproduce_recorded_ss_run(golden_dir):
+    """iLQR_Tracking_SO3.fit on [SO3, SO3Tangent] states with the notebook's callback."""
+    from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_controller import iLQR_Tracking_SO3, iLQR_Tracking_SO3_MS
+    from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_cost import SO3TrackingQuadraticGaussNewtonCost
+    from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_dynamics import SO3Dynamics
+    from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_utilis import SO3, SO3Tangent
+    from scipy.spatial.transform import Rotation
+    g = np.load(os.path.join(golden_dir, "so3_n249_problem.npz"))
+    log = json.load(open(os.path.join(golden_dir, "so3_n249_log.json")))
+    N = 249
+    dyn = SO3Dynamics(g["J"], float(g["dt"]), hessians=False)
+    cost = SO3TrackingQuadraticGaussNewtonCost(g["Q"], g["R"], g["P"], g["q_ref"], g["xi_ref"])
+    q0 = SO3(Rotation.from_euler('zxy', [90., 10., 45.], degrees=True).as_quat())
+    x0 = [q0, SO3Tangent(np.ones((3, 1)) * 1e-1)]
+    ctl = iLQR_Tracking_SO3(dyn, cost, N, hessians=False, rollout='nonlinear')
+    rows = []
+
+    def cb(it, xs, us, J_opt, accepted, converged, grad, alpha, mu, J_hist, xs_hist, us_hist):
+        J_hist.append(J_opt)
+        rows.append((J_opt, grad, alpha, type(xs[0][0]).__name__, us.shape))
+
+    xs, us, J_hist, xs_hist, us_hist, grad_hist = ctl.fit(x0, np.zeros((N, 3)), n_iterations=30, tol_grad_norm=1e-12,
+                                                          on_iteration=cb)
+    its = log["ss"]["iterations"]
+    assert len(rows) == 30 and len(grad_hist) == 30 and us.shape == (N, 3)
+    for k in range(30):
+        assert rows[k][0] == pytest.approx(its[k]["cb_J"], rel=1e-11) and rows[k][1] == pytest.approx(its[k]["grad"], rel=1e-7)
+        assert rows[k][3] == "SO3" and rows[k][4] == (N, 3)
+    assert isinstance(xs[0][0], SO3) and xs[0][1].coeffs().shape == (3,)
+    np.testing.assert_allclose(xs[0][0].rotation(), q0.rotation(), atol=1e-15)
+    # per-knot plugin methods on SO(3) against the oracle's embedded restatement
+    op = ob.embed_so3_problem(g["J"], float(g["dt"]), g["Q"], g["R"], g["P"], g["q_ref"], g["xi_ref"])
+    u = np.array([0.3, -0.2, 0.5])
+    q4, xi6 = ob.embed_so3_state(q0.rotation(), [0.1, 0.2, -0.3])
+    x = [q0, SO3Tangent([0.1, 0.2, -0.3])]
+    fq, fxi = dyn.f(x, u, 0)
+    oq, oxi = ob.f(op, q4, xi6, np.r_[u, 0, 0, 0])
+    np.testing.assert_allclose(fq.rotation(), oq[:3, :3], atol=1e-13); np.testing.assert_allclose(fxi.coeffs(), oxi[:3], atol=1e-13)
+    oFx, oFu = ob.fx_fu(op, q4, xi6)
+    idx = [0, 1, 2, 6, 7, 8]
+    np.testing.assert_allclose(dyn.f_x(x, u, 0), oFx[np.ix_(idx, idx)], atol=1e-12)
+    np.testing.assert_allclose(dyn.f_u(x, u, 0), oFu[np.ix_(idx, [0, 1, 2])], atol=1e-15)
+    l, lx, lxx, lu, luu = ob.cost(op, q4, xi6, np.r_[u, 0, 0, 0], 5)
+    assert cost.l(x, u, 5) == pytest.approx(l, rel=1e-12)
+    np.testing.assert_allclose(cost.l_x(x, u, 5), lx[idx], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(cost.l_xx(x, u, 5), lxx[np.ix_(idx, idx)], rtol=1e-10, atol=1e-9)
+    # MS class runs the recorded merit search
+    ms = iLQR_Tracking_SO3_MS(dyn, cost, N, g["q_ref"], g["xi_ref"], hessians=False, line_search=True, rollout='nonlinear')
+    outs = ms.fit(x0, np.zeros((N, 3)), n_iterations=5, tol_grad_norm=1e-12,
+                  on_iteration=lambda it, xs, us, J, *a: a[-5].append(J))
+    mits = [it for it in log["ms"]["iterations"] if "cb_J" in it]
+    assert len(outs) == 7 and [pytest.approx(mits[k]["cb_J"], rel=1e-12) for k in range(5)] == outs[2]

@@ -4,7 +4,7 @@ import os
 
 from ._build import lib_path
 
-DYN_SE3, DYN_RIGIDBODY, DYN_DRONE = 0, 1, 2
+DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3 = 0, 1, 2, 3
 MODE_MS, MODE_SS = 0, 1
 ST_OK, ST_MAXREG, ST_NODESCENT, ST_NONFINITE = 0, 1, 2, 3
 _ERR = {-1: "bad argument", -2: "workspace too small", -3: "kernel launch failed", -4: "inertia matrix singular"}

@@ -350,8 +350,13 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     Xr.t = v3(r[4], r[5], r[6]);
     V3 ew, ev;
     se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+    // weights: l_xx switches to P at the terminal knot; l and l_x too, except for the SO3 cost which
+    // keeps Q there (traopt_cost.py:434-438, :480-483 vs :530-531)
+    const bool so3 = C.kind == TOLG_DYN_SO3;
     const double* W1 = term ? C.P1 : C.W1;
     const double* W2 = term ? C.P2 : C.W2;
+    const double* G1 = (term && !so3) ? C.P1 : C.W1;
+    const double* G2 = (term && !so3) ? C.P2 : C.W2;
     double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
     double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
     double th2 = dot(ew, ew);
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     for (int a = 0; a < 6; a++) {
       double s1 = 0, s2 = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { s1 += W1[6 * a + k] * e[k]; s2 += W2[6 * a + k] * ve[k]; }
+      for (int k = 0; k < 6; k++) { s1 += G1[6 * a + k] * e[k]; s2 += G2[6 * a + k] * ve[k]; }
       We[a] = s1; W2v[a] = s2;
       l += e[a] * s1 + ve[a] * s2;
     }
@@ -496,6 +501,13 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     mul33(Sv, C.Jv, T1);
 #pragma unroll
     for (int k = 0; k < 9; k++) M22[k] = -T1[k];
+    if (C.kind == TOLG_DYN_SO3) {
+      // SO3Dynamics.f_x (traopt_dynamics.py:385-400): H = J^-1 (skew(w)^T J + skew(J w)) -- the SO(3)
+      // model has no swapped-twist quirk; the unused linear-velocity block is the identity
+      mul33(Sw, C.Ib, T1);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = 0; M21[k] = 0; M22[k] = 0; }
+    }
     double H11[9], H12[9], H21[9], H22[9];
     mul33(C.Ibinv, M11, H11);
     mul33(C.Ibinv, M12, H12);
@@ -1271,8 +1283,9 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
   Xr.t = v3(r[4], r[5], r[6]);
   V3 ew, ev;
   se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
-  const double* W1 = term ? C.P1 : C.W1;
-  const double* W2 = term ? C.P2 : C.W2;
+  const bool so3 = C.kind == TOLG_DYN_SO3;  // the SO3 terminal cost is weighted with Q (App. C-Q3)
+  const double* W1 = (term && !so3) ? C.P1 : C.W1;
+  const double* W2 = (term && !so3) ? C.P2 : C.W2;
   double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
   double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
   double l = 0;
@@ -1452,7 +1465,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   P.ecc[2 * b] = c1;
   P.ecc[2 * b + 1] = c2;
   double dn = P.dn[b], wprev = P.dweight[2 * b + 1], w;
-  if (dn < 1e-12) w = wprev;  // _defect_kappa
+  if (dn < ((C.kind == TOLG_DYN_SO3) ? 1e-14 : 1e-12)) w = wprev;  // _defect_kappa (SE3 :2410, SO3 :1090)
   else w = fmax(10.0, 10.0 + fabs(c1 + 0.5 * c2) / ((1.0 - 0.5) * dn));
   P.dweight[2 * b] = w;
   P.dweight[2 * b + 1] = w;
@@ -1794,7 +1807,7 @@ static int check_problem(const tolg_problem* p) {
   if (!p) return TOLG_E_ARG;
   if (p->N < 1 || !(p->dt > 0)) return TOLG_E_ARG;
   if (p->kind == TOLG_DYN_DRONE) { if (p->m != 4) return TOLG_E_ARG; }
-  else if (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_RIGIDBODY) { if (p->m != 6) return TOLG_E_ARG; }
+  else if (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_RIGIDBODY || p->kind == TOLG_DYN_SO3) { if (p->m != 6) return TOLG_E_ARG; }
   else return TOLG_E_ARG;
   return 0;
 }
@@ -1841,7 +1854,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   if (host_inv6(prob->J, c.Jinv)) { delete h; return TOLG_E_SINGULAR; }
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.Ib[3 * i + j] = prob->J[6 * i + j];
   c.mass = prob->J[6 * 4 + 4];                      // traopt_dynamics.py:663
-  c.grav = (prob->kind == TOLG_DYN_SE3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245
+  c.grav = (prob->kind == TOLG_DYN_SE3 || prob->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++) {
       c.W1[6 * i + j] = prob->Q[12 * i + j];
@@ -2021,7 +2034,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
-      if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
+      if (h->prob.kind != TOLG_DYN_SO3)  // iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20 (:2472)
+        if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
     }

@@ -12,7 +12,7 @@ import torch
 
 from . import _capi
 
-_KIND = {"se3": _capi.DYN_SE3, "rigidbody": _capi.DYN_RIGIDBODY, "drone": _capi.DYN_DRONE}
+_KIND = {"se3": _capi.DYN_SE3, "rigidbody": _capi.DYN_RIGIDBODY, "drone": _capi.DYN_DRONE, "so3": _capi.DYN_SO3}
 
 
 @dataclass
@@ -38,6 +38,20 @@ class TrackingProblem:
     @property
     def m(self):
         return 4 if self.kind == "drone" else 6
+
+
+def embed_so3(J3, dt, Q6, R3, P6, R_ref, w_ref) -> TrackingProblem:
+    """SO(3) tracking problem in the SE(3) layout of the C ABI (include/tolg.h, TOLG_DYN_SO3):
+    zero translation / linear velocity / inputs 3..5, J = blkdiag(J_so3, I3), R = blkdiag(R_so3, I3)."""
+    R_ref = np.asarray(R_ref, float); w_ref = np.asarray(w_ref, float)
+    n = R_ref.shape[0]
+    J = np.eye(6); J[:3, :3] = J3
+    Q = np.zeros((12, 12)); Q[:3, :3] = np.asarray(Q6)[:3, :3]; Q[6:9, 6:9] = np.asarray(Q6)[3:, 3:]
+    P = np.zeros((12, 12)); P[:3, :3] = np.asarray(P6)[:3, :3]; P[6:9, 6:9] = np.asarray(P6)[3:, 3:]
+    R = np.eye(6); R[:3, :3] = R3
+    q_ref = np.tile(np.eye(4), (n, 1, 1)); q_ref[:, :3, :3] = R_ref
+    xi_ref = np.zeros((n, 6)); xi_ref[:, :3] = w_ref
+    return TrackingProblem("so3", J, float(dt), Q, R, P, q_ref, xi_ref)
 
 
 @dataclass

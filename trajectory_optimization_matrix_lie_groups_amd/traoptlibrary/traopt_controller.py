@@ -12,8 +12,8 @@ import numpy as np
 
 from ..solver import BatchedTrackingILQR, TrackingProblem
 from . import _bridge
-from .traopt_cost import ALConstrainedCost, SE3TrackingQuadraticGaussNewtonCost
-from .traopt_dynamics import DroneDynamics, RigidBodyDynamics, SE3Dynamics
+from .traopt_cost import ALConstrainedCost, SE3TrackingQuadraticGaussNewtonCost, SO3TrackingQuadraticGaussNewtonCost
+from .traopt_dynamics import DroneDynamics, RigidBodyDynamics, SE3Dynamics, SO3Dynamics
 
 _KIND = {SE3Dynamics: "se3", RigidBodyDynamics: "rigidbody", DroneDynamics: "drone"}
 _MSG_MAXREG = "exceeded max regularization term"  # traopt_controller.py:2984
@@ -48,6 +48,7 @@ def _xs_list(xs_q, xs_xi):
 
 class _FusedController(BaseController):
     _mode = "ms"
+    _append_grad_on_convergence = False  # iLQR_Tracking_SO3_MS does (traopt_controller.py:1219)
 
     def _common_init(self, dynamics, cost, N, max_reg, hessians, rollout, debug):
         self.dynamics = dynamics
@@ -149,6 +150,8 @@ class _FusedController(BaseController):
                 grad_hist.append(grad)  # SS appends inside fit (traopt_controller.py:1938)
             if conv:  # gradient test fired: the reference breaks before the callback (:2528-2532, :1939-1942)
                 converged = True
+                if ms and self._append_grad_on_convergence:
+                    grad_hist.append(grad)
                 break
             if status == 1:
                 warnings.warn(_MSG_MAXREG)
@@ -296,3 +299,107 @@ class AL_iLQR_Tracking_SE3_MS(BaseController):
         J_hist = list(_bridge.host(res.J_hist)[0][:n])
         grad_hist = list(_bridge.host(res.grad_hist)[0][:n])
         return xs, us, J_hist, [], [], grad_hist, lmbd_hist, mu_hist, violation_hist, nactive_hist
+
+
+# ---------------------------------------------------------------------------------------------------
+# SO(3) controllers: same algorithm, states are [SO3, SO3Tangent] objects (traopt_controller.py:526-1824)
+# ---------------------------------------------------------------------------------------------------
+class _FusedControllerSO3(_FusedController):
+    def _get_solver(self, B):
+        if self._solver is None or self._solver_batch < B:
+            if type(self.dynamics) is not SO3Dynamics or type(self.cost) is not SO3TrackingQuadraticGaussNewtonCost:
+                raise TypeError("the MI355X SO(3) path supports SO3Dynamics with SO3TrackingQuadraticGaussNewtonCost")
+            prob = self.cost._embedded_problem(self.dynamics.J, self.dynamics.dt)
+            if prob.N != self.N:
+                raise ValueError("reference trajectory has %d knots, controller horizon N = %d" % (prob.N + 1, self.N))
+            self._solver = BatchedTrackingILQR(prob, B)
+            self._solver_batch = B
+        return self._solver
+
+    def _attach_al(self, solver, B):
+        return False
+
+    @staticmethod
+    def _wrap_xs(xs):
+        from .traopt_utilis import SO3, SO3Tangent
+        return [[SO3.from_matrix(q[:3, :3]), SO3Tangent(xi[:3])] for q, xi in xs]
+
+    def _fit_so3(self, x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms):
+        from .traopt_dynamics import _so3_state
+        q0, xi0 = _so3_state(x0)
+        us6 = np.zeros((self.N, 6))
+        us6[:, :3] = np.asarray(us_init, float).reshape(self.N, 3)
+        cb = None
+        if on_iteration:
+            def cb(it, xs, us, *rest):
+                rest = list(rest)
+                on_iteration(it, self._wrap_xs(xs), us[:, :3].copy(), *rest)
+        self._action_size_embedded = 6
+        saved = self._action_size
+        self._action_size = 6
+        try:
+            xs, us, J_hist, xs_hist, us_hist, grad_hist, defect_hist = self._fit_single(
+                [q0[0], xi0[0]], us6, n_iterations, tol_grad_norm, tol_d_norm, cb, ms)
+        finally:
+            self._action_size = saved
+        return self._wrap_xs(xs), us[:, :3].copy(), J_hist, xs_hist, us_hist, grad_hist, defect_hist
+
+    def fit_batch(self, x0s, us_init=None, n_iterations=100, tol_grad_norm=None, tol_d_norm=1e-6):
+        """B independent SO(3) fits; returns the FitResult in the embedded SE(3) layout
+        (rotation = xs_q[..., :3, :3], body rate = xs_xi[..., :3], torque = us[..., :3])."""
+        from .traopt_dynamics import _so3_state
+        st = [_so3_state(x) for x in x0s]
+        q = np.concatenate([a for a, _ in st]); xi = np.concatenate([b for _, b in st])
+        B = q.shape[0]
+        us6 = None
+        if us_init is not None:
+            u = np.asarray(us_init, float)
+            u = np.broadcast_to(u, (B,) + u.shape[-2:]) if u.ndim == 2 else u
+            us6 = np.zeros((B, self.N, 6)); us6[:, :, :3] = u
+        solver = self._get_solver(B)
+        tol = self._default_tol if tol_grad_norm is None else tol_grad_norm
+        return solver.fit_batch(q, xi, us6, mode=self._mode, n_iterations=n_iterations, tol_grad_norm=tol,
+                                tol_d_norm=tol_d_norm, **self._options())
+
+
+class iLQR_Tracking_SO3(_FusedControllerSO3):
+    """Single-shooting iLQR on SO(3) (traopt_controller.py:526-1026)."""
+    _mode = "ss"
+    _default_tol = 1e-6
+
+    def __init__(self, dynamics, cost, N, max_reg=1e10, hessians=False, rollout='nonlinear', debug=None):
+        self._common_init(dynamics, cost, N, max_reg, hessians, rollout, debug)
+
+    def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-6, on_iteration=None):
+        xs, us, J_hist, xs_hist, us_hist, grad_hist, _ = self._fit_so3(x0, us_init, n_iterations, tol_grad_norm, 0.0,
+                                                                        on_iteration, ms=False)
+        return xs, us, J_hist, xs_hist, us_hist, grad_hist
+
+
+class iLQR_Tracking_SO3_MS(_FusedControllerSO3):
+    """Multiple-shooting iLQR on SO(3) (traopt_controller.py:1029-1824): 13 line-search alphas."""
+    _mode = "ms"
+    _default_tol = 1e-6
+    _append_grad_on_convergence = True
+
+    def __init__(self, dynamics, cost, N, q_ref, xi_ref, max_reg=1e10, hessians=False, line_search=False,
+                 rollout='linear', debug=None):
+        self._common_init(dynamics, cost, N, max_reg, hessians, rollout, debug)
+        self._q_ref = q_ref
+        self._xi_ref = xi_ref
+        self._line_search = line_search
+        self._defect_mu0 = 10.
+        self._defect_rho = 0.5
+        self._defect_gamma = 0.05
+        self._defect_mu_min = self._defect_mu0
+        self._defect_kappa = 1e-14
+
+    xi_ref = property(lambda self: self._xi_ref)
+    q_ref = property(lambda self: self._q_ref)
+
+    def _options(self):
+        return dict(line_search=self._line_search, rollout=self._rollout_mode, max_reg=self._mu_max)
+
+    def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-6, tol_d_norm=1e-6, on_iteration=None):
+        out = self._fit_so3(x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms=True)
+        return out

@@ -169,3 +169,74 @@ class ALConstrainedCost(BaseCost):
         if terminal:
             return 2 * self.cost.R
         return _bridge.host(self._eval(x, u, i)["luu"])[0]
+
+
+class SO3TrackingQuadraticGaussNewtonCost(BaseCost):
+    """||Log(R Rref^T)||^2_Q1 + ||w - w_ref||^2_Q2 + ||u||^2_R on SO(3) (traopt_cost.py:280-564), with its
+    terminal-weight quirk kept: l and l_x always use Q, only l_xx switches to P."""
+
+    def __init__(self, Q, R, P, q_ref, xi_ref, state_size=(3, 3), action_size=3, **kwargs):
+        self._state_size = state_size[0] + state_size[1]
+        self._pos_state_size = state_size[0]
+        self._vel_state_size = state_size[1]
+        self._action_size = action_size
+        self._q_ref_mats = np.asarray(q_ref, dtype=float)   # (N+1, 3, 3)
+        self._xi_ref = np.asarray(xi_ref, dtype=float)      # (N+1, 3)
+        self._Q = np.asarray(Q, dtype=float)
+        self._R = np.asarray(R, dtype=float)
+        self._P = np.asarray(P, dtype=float)
+        self._probe_solver = None
+
+    state_size = property(lambda self: self._state_size)
+    pos_state_size = property(lambda self: self._pos_state_size)
+    vel_state_size = property(lambda self: self._vel_state_size)
+    action_size = property(lambda self: self._action_size)
+    Q = property(lambda self: self._Q)
+    R = property(lambda self: self._R)
+    P = property(lambda self: self._P)
+
+    @property
+    def N(self):
+        return self._q_ref_mats.shape[0] - 1
+
+    def _embedded_problem(self, J3=None, dt=1.0):
+        from ..solver import embed_so3
+        return embed_so3(np.eye(3) if J3 is None else J3, dt, self._Q, self._R, self._P, self._q_ref_mats, self._xi_ref)
+
+    def _probe(self):
+        if self._probe_solver is None:
+            from ..solver import BatchedTrackingILQR
+            self._probe_solver = BatchedTrackingILQR(self._embedded_problem(), 1)
+        return self._probe_solver
+
+    def _eval(self, x, u, i, terminal=False):
+        from .traopt_dynamics import _so3_state
+        if terminal and int(i) != self.N:
+            raise ValueError("terminal cost is defined at the last knot (i = N)")
+        q, xi = _so3_state(x)
+        u6 = None if u is None else np.r_[np.asarray(u, float).reshape(3), 0, 0, 0].reshape(1, 6)
+        return self._probe().eval_knot(self.N if terminal else int(i), q, xi, u6)
+
+    _IDX = [0, 1, 2, 6, 7, 8]
+
+    def _err(self, x, i):
+        e = _bridge.host(self._eval(x, np.zeros(3), i, terminal=(int(i) == self.N))["err"])[0]
+        return e[:3], e[6:9]
+
+    def l(self, x, u, i, terminal=False):
+        return float(_bridge.host(self._eval(x, u, i, terminal)["l"])[0])
+
+    def l_x(self, x, u, i, terminal=False):
+        return _bridge.host(self._eval(x, u, i, terminal)["lx"])[0][self._IDX]
+
+    def l_u(self, x, u, i, terminal=False):
+        return 2 * self._R @ np.asarray(u, float).reshape(3) if terminal else _bridge.host(self._eval(x, u, i)["lu"])[0][:3]
+
+    def l_xx(self, x, u, i, terminal=False):
+        return _bridge.host(self._eval(x, u, i, terminal)["lxx"])[0][np.ix_(self._IDX, self._IDX)]
+
+    def l_ux(self, x, u, i, terminal=False):
+        return np.zeros((self.action_size, self.state_size))
+
+    def l_uu(self, x, u, i, terminal=False):
+        return 2 * self._R

@@ -155,3 +155,83 @@ class DroneDynamics(_RigidBodyOnSE3):
 
     g = property(lambda self: self._g)
     Pu = property(lambda self: self._Pu)
+
+
+def _so3_state(x):
+    """[SO3, SO3Tangent] (or [R (3,3), w (3,)]) -> embedded SE(3) state arrays."""
+    q, xi = x
+    R = q.rotation() if hasattr(q, "rotation") else np.asarray(q, float)
+    w = xi.coeffs() if hasattr(xi, "coeffs") else np.asarray(xi, float)
+    T = np.eye(4)
+    T[:3, :3] = R
+    return T.reshape(1, 4, 4), np.r_[np.asarray(w, float).reshape(3), 0.0, 0.0, 0.0].reshape(1, 6)
+
+
+class SO3Dynamics(BaseDynamics):
+    """Error-State SO(3) Dynamics Model (traopt_dynamics.py:275-418).  States are [SO3, SO3Tangent]."""
+
+    def __init__(self, J, dt, integration_method="euler", state_size=(3, 3), action_size=3, hessians=False,
+                 debug=None, **kwargs):
+        self._state_size = state_size[0] + state_size[1]
+        self._pos_state_size = state_size[0]
+        self._vel_state_size = state_size[1]
+        self._error_state_size = state_size[0]
+        self._action_size = action_size
+        self._J = np.asarray(J, dtype=float)
+        self._Jinv = np.linalg.inv(self._J)
+        self._dt = dt
+        self._integration_method = integration_method
+        if integration_method == "euler":
+            pass
+        elif integration_method == "rk4":
+            raise ValueError("RK4 not implemented yet.")  # traopt_dynamics.py:318-320
+        else:
+            raise ValueError("Invalid integration method. Choose 'euler' or 'rk4'.")
+        self._has_hessians = hessians
+        self._debug = debug
+        self._probe_solver = None
+
+    state_size = property(lambda self: self._state_size)
+    pos_state_size = property(lambda self: self._pos_state_size)
+    vel_state_size = property(lambda self: self._vel_state_size)
+    action_size = property(lambda self: self._action_size)
+    has_hessians = property(lambda self: self._has_hessians)
+    J = property(lambda self: self._J)
+    Jinv = property(lambda self: self._Jinv)
+    dt = property(lambda self: self._dt)
+
+    def _probe(self):
+        if self._probe_solver is None:
+            J6 = np.eye(6)
+            J6[:3, :3] = self._J
+            self._probe_solver = _bridge.dynamics_probe("so3", J6, self._dt)
+        return self._probe_solver
+
+    def _eval(self, x, u):
+        q, xi = _so3_state(x)
+        return self._probe().eval_knot(0, q, xi, np.r_[np.asarray(u, float).reshape(3), 0, 0, 0].reshape(1, 6))
+
+    def f(self, x, u, i):
+        from .traopt_utilis import SO3, SO3Tangent
+        r = self._eval(x, u)
+        return [SO3.from_matrix(_bridge.host(r["f_q"])[0][:3, :3]), SO3Tangent(_bridge.host(r["f_xi"])[0][:3])]
+
+    fd_euler = f
+
+    def f_x(self, x, u, i):
+        F = _bridge.host(self._eval(x, u)["Fx"])[0]
+        idx = [0, 1, 2, 6, 7, 8]
+        return F[np.ix_(idx, idx)]
+
+    def f_u(self, x, u, i):
+        F = _bridge.host(self._eval(x, u)["Fu"])[0]
+        return F[np.ix_([0, 1, 2, 6, 7, 8], [0, 1, 2])]
+
+    def f_xx(self, x, u, i):
+        raise NotImplementedError
+
+    def f_ux(self, x, u, i):
+        raise NotImplementedError
+
+    def f_uu(self, x, u, i):
+        raise NotImplementedError

@@ -187,3 +187,58 @@ def manifSE32SE3(x):
 
 def parallel_SE32manifSE3(q_ref):
     return [SE32manifSE3(q) for q in q_ref]
+
+
+class SO3:
+    """The slice of ``manifpy.SO3`` the SO(3) scripts touch (main_SO3ddp_tracking_exact.py:87, :150-163):
+    SO3(quaternion xyzw), .rotation(), .coeffs(), .quat().  Group arithmetic (lminus, *, inverse ...) is
+    not reimplemented on the host: the solvers do it on the device."""
+    DoF = 3
+
+    def __init__(self, quaternion):
+        q = np.asarray(quaternion, dtype=float).reshape(4)
+        self._q = q / np.linalg.norm(q)
+
+    @classmethod
+    def from_matrix(cls, R):
+        return cls(Rotation.from_matrix(np.asarray(R, float)).as_quat())
+
+    def rotation(self):
+        return Rotation.from_quat(self._q).as_matrix()
+
+    def coeffs(self):
+        return self._q.copy()
+
+    def quat(self):
+        return self._q.copy()
+
+    def transform(self):
+        T = np.eye(4)
+        T[:3, :3] = self.rotation()
+        return T
+
+
+class SO3Tangent:
+    """manifpy.SO3Tangent holder: coefficient vector (3,) and the scalar arithmetic scripts use."""
+
+    def __init__(self, w):
+        self._w = np.asarray(w, dtype=float).reshape(3).copy()
+
+    def coeffs(self):
+        return self._w.copy()
+
+    def __mul__(self, s):
+        return SO3Tangent(self._w * float(s))
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return SO3Tangent(self._w + o._w)
+
+    def __sub__(self, o):
+        return SO3Tangent(self._w - o._w)
+
+
+def SO32manifSO3(x):
+    """traopt_utilis.py:291-297"""
+    return SO3(Rotation.from_matrix(x).as_quat())
