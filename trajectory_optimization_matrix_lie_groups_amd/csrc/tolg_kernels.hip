@@ -115,8 +115,17 @@ enum {
   REC_LUU = 139, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
   REC_F = 145
 };
-#define RIDX(i, f, b) ((((size_t)(i)) * REC_F + (size_t)(f)) * (size_t)P.Bp + (size_t)(b))
-#define GKIDX(i, u, b, j) (((((size_t)(i)) * (size_t)P.m + (size_t)(u)) * 13 + (size_t)(j)) * (size_t)P.Bp + (size_t)(b))
+// Records and gains are interleaved by four trajectories: [knot][b / 4][field][b % 4].  The four
+// trajectories of one K2 wavefront then own one contiguous 4.6 KB run per knot (every 64-byte
+// sector it touches is entirely its own), while K1/K3 (one thread per trajectory) still move whole
+// 32-byte groups.  With the plain [knot][field][Bp] layout K2 fetched every 128-byte line four times.
+#define RIDX(i, f, b) (((size_t)(i)) * REC_F * (size_t)P.Bp + ((((size_t)(b)) >> 2) * REC_F + (size_t)(f)) * 4 + (((size_t)(b)) & 3))
+#define GKIDX(i, u, b, j) \
+  (((size_t)(i)) * 13 * (size_t)P.m * (size_t)P.Bp + ((((size_t)(b)) >> 2) * 13 * (size_t)P.m + (size_t)(u) * 13 + (size_t)(j)) * 4 + (((size_t)(b)) & 3))
+// byte offsets for the buffer accessors: field stride and the lane's base inside one knot
+#define REC_SR 32u
+#define REC_VR(b) ((unsigned)((b) >> 2) * (REC_F * 32u) + (unsigned)((b) & 3) * 8u)
+#define GK_VG(b, M_) ((unsigned)((b) >> 2) * (13u * (M_) * 32u) + (unsigned)((b) & 3) * 8u)
 __host__ __device__ inline int sym6(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,12 +871,13 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // (gravity models) build their A21 column from R^T e3 with per-lane constants
   const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const unsigned vT = vb + (unsigned)fT * sB, vM = vb + (unsigned)fM * sB, vBt = vb + (unsigned)fB * sB;
-  const unsigned vG = vb + (unsigned)(j < 13 ? j : 12) * sB;
-  const unsigned vUU = vb + (unsigned)(REC_LUU + (j < M ? j : 0)) * sB;
+  const unsigned vr = REC_VR(b);
+  const unsigned vT = vr + (unsigned)fT * REC_SR, vM = vr + (unsigned)fM * REC_SR, vBt = vr + (unsigned)fB * REC_SR;
+  const unsigned vG = GK_VG(b, M) + (unsigned)(j < 13 ? j : 12) * REC_SR;
+  const unsigned vUU = vr + (unsigned)(REC_LUU + (j < M ? j : 0)) * REC_SR;
   unsigned vL[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) vL[r] = vb + (unsigned)fL[r] * sB;
+  for (int r = 0; r < 6; r++) vL[r] = vr + (unsigned)fL[r] * REC_SR;
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   const double mB = ((j >= 6 && j < 12) || j == 12) ? 1.0 : 0.0;
   double Cg[3][6];
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, vb, (REC_LX + 6 + r) * sB);
+      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, REC_VR(b), (REC_LX + 6 + r) * REC_SR);
       V[r] = mLT * t1;
       double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
       V[6 + r] = mvec * t2 + p2;
@@ -900,22 +910,22 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      in.t[r] = bld(rR, vT, r * sB);
-      in.m[r] = bld(rR, vM, r * sB);
+      in.t[r] = bld(rR, vT, r * REC_SR);
+      in.m[r] = bld(rR, vM, r * REC_SR);
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) in.bt[r] = bld(rR, vBt, r * sB);
+    for (int r = 0; r < 6; r++) in.bt[r] = bld(rR, vBt, r * REC_SR);
     if (grav) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, vb, (REC_RTE + a) * sB);
+      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), (REC_RTE + a) * REC_SR);
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       in.lt[r] = bld(rR, vL[r], 0);
-      in.lb[r] = bld(rR, vb, (REC_LX + 6 + r) * sB);
+      in.lb[r] = bld(rR, REC_VR(b), (REC_LX + 6 + r) * REC_SR);
     }
 #pragma unroll
-    for (int a = 0; a < M; a++) in.lu[a] = bld(rR, vb, (REC_LU + a) * sB);
+    for (int a = 0; a < M; a++) in.lu[a] = bld(rR, REC_VR(b), (REC_LU + a) * REC_SR);
     in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
   };
 
@@ -1055,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
     if (act && j < 13) {
 #pragma unroll
-      for (int u = 0; u < M; u++) bst(rG, vG, (unsigned)(u * 13) * sB, Kh[u]);
+      for (int u = 0; u < M; u++) bst(rG, vG, (unsigned)(u * 13) * REC_SR, Kh[u]);
     }
     // ---- V <- Qh + Q_ux^T [K | k]   (== Eq. 11b/11c of traopt_controller.py:2998-3003 for the
     // exact gains), then symmetrise the matrix columns through LDS (traopt_controller.py:3004)
@@ -1169,19 +1179,20 @@ TOLG_DEV State roll_load_state(const Params& P, int i, unsigned vb, unsigned sB)
 }
 template <int M, bool ALPHA1>
 TOLG_DEV void roll_load(const Params& P, int i, unsigned vb, unsigned sB, RollIn<M>& R) {
+  const int b = (int)(vb >> 3);
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
   __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
 #pragma unroll
-  for (int k = 0; k < M * 13; k++) R.G[k] = bld(rG, vb, (unsigned)k * sB);
+  for (int k = 0; k < M * 13; k++) R.G[k] = bld(rG, GK_VG(b, M), (unsigned)k * REC_SR);
 #pragma unroll
   for (int a = 0; a < M; a++) R.u[a] = bld(rU, vb, a * sB);
   if constexpr (ALPHA1) {
-    R.Mx.q.x = bld(rR, vb, (REC_M + 0) * sB); R.Mx.q.y = bld(rR, vb, (REC_M + 1) * sB);
-    R.Mx.q.z = bld(rR, vb, (REC_M + 2) * sB); R.Mx.q.w = bld(rR, vb, (REC_M + 3) * sB);
-    R.Mx.t = v3(bld(rR, vb, (REC_M + 4) * sB), bld(rR, vb, (REC_M + 5) * sB), bld(rR, vb, (REC_M + 6) * sB));
-    R.cw = v3(bld(rR, vb, (REC_C + 0) * sB), bld(rR, vb, (REC_C + 1) * sB), bld(rR, vb, (REC_C + 2) * sB));
-    R.cv = v3(bld(rR, vb, (REC_C + 3) * sB), bld(rR, vb, (REC_C + 4) * sB), bld(rR, vb, (REC_C + 5) * sB));
+    R.Mx.q.x = bld(rR, REC_VR(b), (REC_M + 0) * REC_SR); R.Mx.q.y = bld(rR, REC_VR(b), (REC_M + 1) * REC_SR);
+    R.Mx.q.z = bld(rR, REC_VR(b), (REC_M + 2) * REC_SR); R.Mx.q.w = bld(rR, REC_VR(b), (REC_M + 3) * REC_SR);
+    R.Mx.t = v3(bld(rR, REC_VR(b), (REC_M + 4) * REC_SR), bld(rR, REC_VR(b), (REC_M + 5) * REC_SR), bld(rR, REC_VR(b), (REC_M + 6) * REC_SR));
+    R.cw = v3(bld(rR, REC_VR(b), (REC_C + 0) * REC_SR), bld(rR, REC_VR(b), (REC_C + 1) * REC_SR), bld(rR, REC_VR(b), (REC_C + 2) * REC_SR));
+    R.cv = v3(bld(rR, REC_VR(b), (REC_C + 3) * REC_SR), bld(rR, REC_VR(b), (REC_C + 4) * REC_SR), bld(rR, REC_VR(b), (REC_C + 5) * REC_SR));
   }
 }
 
@@ -1217,7 +1228,7 @@ TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigne
       __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
       double d[12];
 #pragma unroll
-      for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+      for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
       State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, R.u);
       Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                        se3_inverse(Fo.X));
@@ -1232,7 +1243,7 @@ TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigne
     double lin[12], d[12];
     fx_apply<M>(P, C, i, b, e, du, lin);
 #pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, vb, (REC_D + a) * sB);
+    for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
     Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
     Nx.X = se3_project(se3_compose(Sx.X, D));
@@ -1343,9 +1354,9 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
     double u[M], un[M], du[M];
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double sacc = alpha * bld(rG, vb, (unsigned)(a * 13 + 12) * sB);
+      double sacc = alpha * bld(rG, GK_VG(b, M), (unsigned)(a * 13 + 12) * REC_SR);
 #pragma unroll
-      for (int k = 0; k < 12; k++) sacc += bld(rG, vb, (unsigned)(a * 13 + k) * sB) * e[k];
+      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), (unsigned)(a * 13 + k) * REC_SR) * e[k];
       u[a] = bld(rU, vb, a * sB);
       du[a] = sacc;
       un[a] = u[a] + sacc;
@@ -1357,7 +1368,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
       if constexpr (MS) {
         double d[12];
 #pragma unroll
-        for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+        for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
         State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, u);
         Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                               se3_inverse(Fo.X));
@@ -1377,7 +1388,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
       double lin[12], d[12];
       fx_apply<M>(P, C, i, b, e, du, lin);
 #pragma unroll
-      for (int a = 0; a < 12; a++) d[a] = MS ? alpha * bld(rR, vb, (REC_D + a) * sB) : 0.0;
+      for (int a = 0; a < 12; a++) d[a] = MS ? alpha * bld(rR, REC_VR(b), (REC_D + a) * REC_SR) : 0.0;
       State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
       Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
       Nx.X = se3_project(se3_compose(Sx.X, D));
@@ -1427,12 +1438,12 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
     // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
     const double* W2 = (i == N) ? C.P2 : C.W2;
 #pragma unroll
-    for (int a = 0; a < 12; a++) c1 += bld(rR, vb, (REC_LX + a) * sB) * e[a];
+    for (int a = 0; a < 12; a++) c1 += bld(rR, REC_VR(b), (REC_LX + a) * REC_SR) * e[a];
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        c2 += e[a] * bld(rR, vb, (unsigned)(REC_LXX + sym6(a, k)) * sB) * e[k];
+        c2 += e[a] * bld(rR, REC_VR(b), (unsigned)(REC_LXX + sym6(a, k)) * REC_SR) * e[k];
         c2 += e[6 + a] * 2.0 * W2[6 * a + k] * e[6 + k];
       }
     if (i == N) break;
@@ -1440,22 +1451,22 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
     double du[M];
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double sacc = bld(rG, vb, (unsigned)(a * 13 + 12) * sB);
+      double sacc = bld(rG, GK_VG(b, M), (unsigned)(a * 13 + 12) * REC_SR);
 #pragma unroll
-      for (int k = 0; k < 12; k++) sacc += bld(rG, vb, (unsigned)(a * 13 + k) * sB) * e[k];
+      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), (unsigned)(a * 13 + k) * REC_SR) * e[k];
       du[a] = sacc;
     }
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      c1 += bld(rR, vb, (REC_LU + a) * sB) * du[a];
+      c1 += bld(rR, REC_VR(b), (REC_LU + a) * REC_SR) * du[a];
 #pragma unroll
       for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
-      c2 += du[a] * bld(rR, vb, (REC_LUU + a) * sB) * du[a];
+      c2 += du[a] * bld(rR, REC_VR(b), (REC_LUU + a) * REC_SR) * du[a];
     }
     double lin[12], d[12];
     fx_apply<M>(P, C, i, b, e, du, lin);
 #pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = bld(rR, vb, (REC_D + a) * sB);
+    for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
     Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
     Sn.X = se3_project(se3_compose(Sx.X, D));
