@@ -24,6 +24,25 @@ ALG_BYTES_PER_KNOT_ITER = 448  # read+write of (q 4x4, xi 6, u 6
 ALG_FLOPS_PER_KNOT_ITER = 25e3  # dense count, SURVEY.md §8d (secondary figure)
 
 
+def measured_traffic(kernel="k_backward"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes).  PMC counters cannot be read
+    from inside the timed process, so this is the figure of the profiled run, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for name, v in d["kernels"].items():
+            if kernel in name:
+                return v["hbm_bytes_per_launch_fetch_doubled"], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(prob, x0_q, x0_xi, us0, iters):
     """The CPU oracle (oracle/tolg_oracle.c: the parity-checked port of the reference algorithm),
     OpenMP over trajectories on this host's cores, same workload, `iters` iterations."""
@@ -121,6 +140,7 @@ def main():
         t_bwd = ms_b / max(n_b, 1) * 1e-3
         alg_bytes = ALG_BYTES_PER_KNOT_ITER * B * N
         achieved = alg_bytes / t_bwd / 1e9 if t_bwd > 0 else None
+        traffic, traffic_src = measured_traffic() if (B == 4096 and N == 200) else (None, None)
         line = {
             "metric": "DDP iterations/sec at batch x horizon = 4096 x 200 (SE3 tracking)",
             "value": value, "unit": "batch-iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -135,7 +155,8 @@ def main():
                                               "linearize": ms_l / max(n_b, 1)},
                        "final_gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "k_backward", "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_avg_ms": t_bwd * 1e3,
                          "note": "fp64 VALU-bound by construction (SURVEY §8d): whole-step fp64 fraction = "

@@ -1258,20 +1258,29 @@ TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigne
 }
 
 template <int M, bool LINEAR, bool ALPHA1>
-__global__ __launch_bounds__(64) void k_rollout(Params P, double alpha) {
+__global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
+  // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
+  // knots (K1, on a second stream) overlaps the remaining sequential sweep
   const Consts& C = *P.c;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
-  const int N = P.N;
+  // the sweep is the critical path: its waves win issue arbitration over the re-linearisation waves
+  // that share their SIMDs
+  __builtin_amdgcn_s_setprio(3);
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);  // new trajectory, knot i
-  store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
-  State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
-  for (int i = 0; i < N; i += 2) {
-    if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
+  State Sn;  // new trajectory, knot i
+  if (i0 == 0) {
+    Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+    store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
+  } else {
+    Sn = load_state_b(mkbuf(P.cand + (size_t)13 * P.Bp * i0, 13 * sB), vb, sB);
+  }
+  State Sa = roll_load_state(P, i0, vb, sB), Sb = Sa;
+  for (int i = i0; i < i1; i += 2) {
+    if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i, b, vb, sB, alpha, Sa, Sn);
-    if (i + 1 >= N) break;
-    if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
+    if (i + 1 >= i1) break;
+    if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i + 1, b, vb, sB, alpha, Sb, Sn);
   }
 }
@@ -1733,6 +1742,8 @@ struct tolg_handle_s {
   int run_it;         // iterations issued so far
   bool running;
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
+  hipStream_t st2;        // library-owned second stream for the rollout / re-linearisation overlap
+  hipEvent_t seg_ev[8];
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -1858,6 +1869,9 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->running = false;
   h->run_it = 0;
   h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
+  h->st2 = nullptr;
+  if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
+  for (auto& e : h->seg_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
   c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
@@ -1925,6 +1939,8 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
 extern "C" void tolg_destroy(tolg_handle_t h) {
   if (!h) return;
   for (auto e : h->ev) (void)hipEventDestroy(e);
+  for (auto e : h->seg_ev) (void)hipEventDestroy(e);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
   delete h;
 }
 
@@ -2000,12 +2016,14 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
   return 0;
 }
 template <int M>
-static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear, int ms = 1) {
+static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, double alpha, int linear, int ms = 1,
+                          int i0 = 0, int i1 = -1) {
+  if (i1 < 0) i1 = P.N;
   Timed t(h, st, 1);
   dim3 grid((P.Bp + 63) / 64), blk(64);
-  if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha);
-  else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha);
-  else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha);
+  if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha, i0, i1);
+  else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha, i0, i1);
+  else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha, i0, i1);
   LAUNCH_CHECK();
   return 0;
 }
@@ -2034,7 +2052,24 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
-    if (!opt->line_search) {
+    if (!opt->line_search && h->st2 && P.N >= 8) {
+      // accept-always rollout: issue it in NSEG segments on the caller's stream and re-linearise every
+      // finished segment on the library's second stream meanwhile (K3 keeps 64 waves busy, K1 the rest)
+      const int NSEG = 4;
+      for (int sg = 0; sg < NSEG; sg++) {
+        const int i0 = (int)((long)P.N * sg / NSEG), i1 = (int)((long)P.N * (sg + 1) / NSEG);
+        if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear, 1, i0, i1))) return rc;
+        if (hipEventRecord(h->seg_ev[sg], st) != hipSuccess) return TOLG_E_LAUNCH;
+        if (hipStreamWaitEvent(h->st2, h->seg_ev[sg], 0) != hipSuccess) return TOLG_E_LAUNCH;
+        const int k1 = (sg == NSEG - 1) ? P.N + 1 : i1;  // the last segment also takes the terminal knot
+        if ((rc = run_linearize<M>(h, P, h->st2, P.cand, P.cand_u, P.cur, P.cur_u, 1, i0, k1 - i0))) return rc;
+      }
+      if (hipEventRecord(h->seg_ev[NSEG], h->st2) != hipSuccess) return TOLG_E_LAUNCH;
+      if (hipStreamWaitEvent(st, h->seg_ev[NSEG], 0) != hipSuccess) return TOLG_E_LAUNCH;
+      hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+      LAUNCH_CHECK();
+      continue;
+    } else if (!opt->line_search) {
       if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
     } else {
       hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
