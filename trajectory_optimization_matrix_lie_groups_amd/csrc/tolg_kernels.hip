@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -929,9 +930,10 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
   };
 
-  auto step = [&](int i, const BwdIn& in) {
+  auto step = [&](int i, BwdIn& in) {
     __amdgpu_buffer_rsrc_t rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
     double A[12], Lc[12], lu[M];
+    const double luu_i = in.luu;
 #pragma unroll
     for (int r = 0; r < 3; r++) { A[r] = mT * in.t[r]; A[3 + r] = mM * in.m[r]; }
 #pragma unroll
@@ -968,6 +970,13 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       rank1_bi_23(Qh, A[9], Z[9]); rank1_bi_23(Qh, A[10], Z[10]); rank1_bi_23(Qh, A[11], Z[11]);
     }
 
+    // The raw fields of this knot are consumed (A, Lc, lu, luu_i live in their own registers from here
+    // on): request the next knot's fields into the same buffer now, so they arrive while the
+    // regularisation / Cholesky / gain / V-update half of the step runs.  One buffer instead of a
+    // ping-pong pair keeps the loads in VGPRs (with two, the allocator parked them in AGPRs and had to
+    // wait for them right away to copy them back).
+    if (i > 0) load_knot(i - 1, in);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
     double Quh[M], Kh[M];
     bool done = !act;  // inactive trajectories skip the loop body but keep EXEC rows uniform
@@ -1006,7 +1015,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
         double Quu[M];
 #pragma unroll
-        for (int u = 0; u < M; u++) Quu[u] = Rcol[u] + ((j == u) ? in.luu : 0.0);
+        for (int u = 0; u < M; u++) Quu[u] = Rcol[u] + ((j == u) ? luu_i : 0.0);
         quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
         quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
         // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
@@ -1090,15 +1099,9 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
   };
 
-  BwdIn Ia, Ib;
-  load_knot(N - 1, Ia);
-  for (int i = N - 1; i >= 0; i -= 2) {
-    if (i - 1 >= 0) load_knot(i - 1, Ib);
-    step(i, Ia);
-    if (i - 1 < 0) break;
-    if (i - 2 >= 0) load_knot(i - 2, Ia);
-    step(i - 1, Ib);
-  }
+  BwdIn in;
+  load_knot(N - 1, in);
+  for (int i = N - 1; i >= 0; i--) step(i, in);
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
   double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
   if (act && j == 0) {
@@ -1164,27 +1167,38 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
   }
 }
 
-// What one rollout step reads.  The nominal state (needed first, by Log) is fetched one knot ahead
-// (ping-pong registers); gains, controls and the rollout factors are requested at the top of the
-// step and arrive while Log runs.  64 waves cannot hide memory latency any other way.
+// What one rollout step reads.  Four lanes share a trajectory: every lane runs the (scalar) Log / Exp
+// chain redundantly, but the gain product K dx -- the bulk of the loads and FMAs -- is split by rows
+// (lane q owns rows q and q + 4) and the resulting du is broadcast inside the quad with DPP
+// quad_perm.  The nominal state (needed first, by Log) is fetched one knot ahead (ping-pong
+// registers); gains, controls and the rollout factors are requested at the top of the step and arrive
+// while Log runs.  A few hundred waves cannot hide memory latency any other way.
 template <int M>
 struct RollIn {
-  double G[M * 13];  // gains [K | k], row-major
+  double G[2][13];   // gain rows q and q + 4 of [K | k]
   double u[M];
   Pose Mx;           // REC_M
   V3 cw, cv;         // REC_C
 };
+template <int L>
+TOLG_DEV double quad_bcast(double x) {  // value of x in lane L of this lane's quad
+  return __builtin_amdgcn_update_dpp(0.0, x, L | (L << 2) | (L << 4) | (L << 6), 0xf, 0xf, false);
+}
 TOLG_DEV State roll_load_state(const Params& P, int i, unsigned vb, unsigned sB) {
   return load_state_b(mkbuf(P.cur + (size_t)13 * P.Bp * i, 13 * sB), vb, sB);
 }
 template <int M, bool ALPHA1>
-TOLG_DEV void roll_load(const Params& P, int i, unsigned vb, unsigned sB, RollIn<M>& R) {
-  const int b = (int)(vb >> 3);
+TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsigned sB, RollIn<M>& R) {
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
   __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+  const unsigned vg0 = GK_VG(b, M) + (unsigned)(q * 13) * REC_SR;
+  const unsigned vg1 = GK_VG(b, M) + (unsigned)(((q + 4 < M) ? q + 4 : q) * 13) * REC_SR;  // M = 4: second row unused
 #pragma unroll
-  for (int k = 0; k < M * 13; k++) R.G[k] = bld(rG, GK_VG(b, M), (unsigned)k * REC_SR);
+  for (int k = 0; k < 13; k++) {
+    R.G[0][k] = bld(rG, vg0, (unsigned)k * REC_SR);
+    R.G[1][k] = bld(rG, vg1, (unsigned)k * REC_SR);
+  }
 #pragma unroll
   for (int a = 0; a < M; a++) R.u[a] = bld(rU, vb, a * sB);
   if constexpr (ALPHA1) {
@@ -1197,25 +1211,32 @@ TOLG_DEV void roll_load(const Params& P, int i, unsigned vb, unsigned sB, RollIn
 }
 
 template <int M, bool LINEAR, bool ALPHA1>
-TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigned vb, unsigned sB, double alpha,
-                         const State& So, const State& Sn) {
+TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, int q, bool writer, unsigned vb, unsigned sB,
+                         double alpha, const State& So, const State& Sn) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
   RollIn<M> R;
-  roll_load<M, ALPHA1>(P, i, vb, sB, R);  // in flight while Log runs
+  roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R);  // in flight while Log runs
+  __builtin_amdgcn_sched_barrier(0);
   // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
   V3 ew, ev;
   se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
   double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
                   Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
-  double un[M], du[M];
+  // du = alpha k + K dx: this lane's two rows, then quad broadcast (identical bits in all four lanes)
+  double mine[2];
 #pragma unroll
-  for (int a = 0; a < M; a++) {
-    double s = alpha * R.G[a * 13 + 12];
+  for (int sidx = 0; sidx < 2; sidx++) {
+    double sacc = alpha * R.G[sidx][12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) s += R.G[a * 13 + k] * e[k];
-    du[a] = s;
-    un[a] = R.u[a] + s;
+    for (int k = 0; k < 12; k++) sacc += R.G[sidx][k] * e[k];
+    mine[sidx] = sacc;
   }
+  double un[M], du[M];
+  du[0] = quad_bcast<0>(mine[0]); du[1] = quad_bcast<1>(mine[0]);
+  du[2] = quad_bcast<2>(mine[0]); du[3] = quad_bcast<3>(mine[0]);
+  if constexpr (M == 6) { du[4] = quad_bcast<0>(mine[1]); du[5] = quad_bcast<1>(mine[1]); }
+#pragma unroll
+  for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
   State Nx;
   if constexpr (!LINEAR) {
     State Fn = dyn_f<M>(C, Sn, un);
@@ -1250,10 +1271,12 @@ TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, unsigne
     Nx.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
     Nx.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
   }
-  __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
+  if (writer) {
+    __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
 #pragma unroll
-  for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
-  store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+    for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
+    store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+  }
   return Nx;
 }
 
@@ -1262,26 +1285,31 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
   const Consts& C = *P.c;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.Bp || !P.active[b]) return;
-  // the sweep is the critical path: its waves win issue arbitration over the re-linearisation waves
-  // that share their SIMDs
-  __builtin_amdgcn_s_setprio(3);
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  int b = t >> 2;
+  const int q = t & 3;
+  // quads past the batch replay the last trajectory (DPP needs whole quads alive) and store nothing
+  const bool live = b < P.Bp;
+  if (!live) b = P.Bp - 1;
+  if (!P.active[b]) return;  // quad-uniform
+  const bool writer = live && q == 0;  // one lane of a live quad stores
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   State Sn;  // new trajectory, knot i
   if (i0 == 0) {
     Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
-    store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
+    if (writer) store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
   } else {
     Sn = load_state_b(mkbuf(P.cand + (size_t)13 * P.Bp * i0, 13 * sB), vb, sB);
   }
   State Sa = roll_load_state(P, i0, vb, sB), Sb = Sa;
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
-    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i, b, vb, sB, alpha, Sa, Sn);
+    __builtin_amdgcn_sched_barrier(0);
+    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i, b, q, writer, vb, sB, alpha, Sa, Sn);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
-    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i + 1, b, vb, sB, alpha, Sb, Sn);
+    __builtin_amdgcn_sched_barrier(0);
+    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
   }
 }
 
@@ -1870,7 +1898,11 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->run_it = 0;
   h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
   h->st2 = nullptr;
-  if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
+  // Overlapping the segmented rollout with the re-linearisation on a second stream is OFF by default:
+  // measured on MI355X at 4096x200 it loses (K1's 12.9k waves slow the 256 latency-bound rollout waves
+  // by 1.5x: 559 vs 602 batch-iterations/s).  TOLG_OVERLAP=1 enables it for A/B runs.
+  const char* ov = getenv("TOLG_OVERLAP");
+  if (!(ov && ov[0] == '1') || hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
   for (auto& e : h->seg_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
@@ -2020,7 +2052,7 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
                           int i0 = 0, int i1 = -1) {
   if (i1 < 0) i1 = P.N;
   Timed t(h, st, 1);
-  dim3 grid((P.Bp + 63) / 64), blk(64);
+  dim3 grid((P.Bp * 4 + 63) / 64), blk(64);  // four lanes per trajectory
   if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha, i0, i1);
   else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha, i0, i1);
   else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha, i0, i1);
