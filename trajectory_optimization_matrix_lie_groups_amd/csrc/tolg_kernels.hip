@@ -13,6 +13,7 @@
 // Device layout: structure-of-arrays with the batch index fastest, poses as unit quaternion +
 // translation (see tolg_lie.h).  The 4x4 layout of the reference exists only at the C ABI.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -44,6 +45,16 @@ struct Consts {
   // row-major each, no m*g: App. C-Q2)
   double Llin[3][36];
 };
+
+// Device-side view of the constants used by the three hot kernels: address space 4 (constant), so
+// that uniform reads become scalar loads (lgkmcnt) and never queue behind in-flight record
+// prefetches on vmcnt.  Cold kernels keep the generic pointer: with a few hundred invariant scalar
+// loads hoisted out of their knot loops they would only spill SGPRs.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(4))) Consts DConsts;
+#else
+typedef Consts DConsts;  // the host pass only parses the kernels
+#endif
 
 struct Params {
   const Consts* c;
@@ -172,13 +183,13 @@ TOLG_DEV V3 mv33(const double* A, V3 x) {
             A[6] * x.x + A[7] * x.y + A[8] * x.z);
 }
 // entry (6 + r, u) of F_u (m columns), r = 0..5
-template <int M>
-TOLG_DEV double fu_entry(const Consts& C, int r, int u) {
+template <int M, class CT>
+TOLG_DEV double fu_entry(const CT& C, int r, int u) {
   if (r < 3) return (u < 3) ? C.Bt[3 * r + u] : 0.0;
   return (u >= 3) ? C.Bb[3 * (r - 3) + (u - 3)] : 0.0;
 }
-template <int M>
-TOLG_DEV State dyn_f(const Consts& C, const State& S, const double (&u)[M]) {
+template <int M, class CT>
+TOLG_DEV State dyn_f(const CT& C, const State& S, const double (&u)[M]) {
   State F;
   const double dt = C.dt;
   Pose E = se3_exp(dt * S.w, dt * S.v);
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
                                                     double* __restrict__ dst_u, int ms, int i0, int ni) {
   // ms: 1 multiple shooting, 0 single shooting, 2 probe (tolg_eval_knot: f(x,u) goes to REC_M/REC_C,
   // the tracking error to REC_D, nothing is read from knot i+1); knots [i0, i0 + ni)
-  const Consts& C = *P.c;
+  const DConsts& C = *(const DConsts*)P.c;
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (size_t)ni * P.Bp) return;
   const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
@@ -833,7 +844,7 @@ TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
 
 template <int M>
 __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
-  const Consts& C = *P.c;
+  const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
   const bool act = P.active[b] != 0;
@@ -1210,8 +1221,8 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
   }
 }
 
-template <int M, bool LINEAR, bool ALPHA1>
-TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, int q, bool writer, unsigned vb, unsigned sB,
+template <int M, bool LINEAR, bool ALPHA1, class CT>
+TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool writer, unsigned vb, unsigned sB,
                          double alpha, const State& So, const State& Sn) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
   RollIn<M> R;
@@ -1262,7 +1273,7 @@ TOLG_DEV State roll_step(const Params& P, const Consts& C, int i, int b, int q, 
   } else {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
     double lin[12], d[12];
-    fx_apply<M>(P, C, i, b, e, du, lin);
+    fx_apply<M>(P, *P.c, i, b, e, du, lin);
 #pragma unroll
     for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
@@ -1284,7 +1295,8 @@ template <int M, bool LINEAR, bool ALPHA1>
 __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
-  const Consts& C = *P.c;
+  typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
+  const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * 64 + threadIdx.x;
   int b = t >> 2;
   const int q = t & 3;
