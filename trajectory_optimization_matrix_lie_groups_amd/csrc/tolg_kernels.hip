@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
   typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
   const CT& C = *(const CT*)P.c;
-  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int b = t >> 2;
   const int q = t & 3;
   // quads past the batch replay the last trajectory (DPP needs whole quads alive) and store nothing
@@ -1782,7 +1782,8 @@ struct tolg_handle_s {
   int run_it;         // iterations issued so far
   bool running;
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
-  hipStream_t st2;        // library-owned second stream for the rollout / re-linearisation overlap
+  hipStream_t st2;        // library-owned streams for the rollout / re-linearisation overlap:
+  hipStream_t st_roll;    // st2 runs K1, st_roll (null: the caller's stream) the segmented K3
   hipEvent_t seg_ev[8];
   // timing
   bool timing;
@@ -1909,12 +1910,37 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->running = false;
   h->run_it = 0;
   h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
-  h->st2 = nullptr;
-  // Overlapping the segmented rollout with the re-linearisation on a second stream is OFF by default:
-  // measured on MI355X at 4096x200 it loses (K1's 12.9k waves slow the 256 latency-bound rollout waves
-  // by 1.5x: 559 vs 602 batch-iterations/s).  TOLG_OVERLAP=1 enables it for A/B runs.
-  const char* ov = getenv("TOLG_OVERLAP");
-  if (!(ov && ov[0] == '1') || hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
+  h->st2 = h->st_roll = nullptr;
+  // Rollout / re-linearisation overlap is OFF by default.  Measured on MI355X at 4096x200 (batch-
+  // iterations/s): no overlap 655; K1 segments on a second stream behind the segmented K3 (=1) 607;
+  // the same with disjoint compute-unit masks, K3 on a quarter of the CUs (=2) 448.  Both kernels
+  // stream from HBM through the per-CU address/L1 path (one CU sustains ~10 B/cycle of misses), so K3
+  // needs all 256 CUs to itself: sharing them with K1 or packing K3's waves onto fewer CUs both lose.
+  // TOLG_OVERLAP=1|2 keeps the two variants for A/B runs; TOLG_ROLL_CUS sets the K3 share for =2.
+  {
+    const char* ov = getenv("TOLG_OVERLAP");
+    const int mode = ov ? atoi(ov) : 0;
+    int dev = 0, ncu = 0;
+    if (mode >= 1 && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu >= 8) {
+      if (mode == 1) {
+        if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
+      } else {
+        const char* rc_env = getenv("TOLG_ROLL_CUS");
+        int nroll = rc_env ? atoi(rc_env) : ncu / 4;
+        if (nroll < 1 || nroll >= ncu) nroll = ncu / 4;
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> m_roll(words, 0u), m_lin(words, 0u);
+        for (int cu = 0; cu < ncu; cu++) (cu < nroll ? m_roll : m_lin)[cu / 32] |= 1u << (cu % 32);
+        if (hipExtStreamCreateWithCUMask(&h->st_roll, (uint32_t)words, m_roll.data()) != hipSuccess) h->st_roll = nullptr;
+        if (!h->st_roll || hipExtStreamCreateWithCUMask(&h->st2, (uint32_t)words, m_lin.data()) != hipSuccess) {
+          if (h->st_roll) (void)hipStreamDestroy(h->st_roll);
+          h->st_roll = h->st2 = nullptr;
+        }
+        (void)hipGetLastError();
+      }
+    }
+  }
   for (auto& e : h->seg_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
@@ -1985,6 +2011,7 @@ extern "C" void tolg_destroy(tolg_handle_t h) {
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (auto e : h->seg_ev) (void)hipEventDestroy(e);
   if (h->st2) (void)hipStreamDestroy(h->st2);
+  if (h->st_roll) (void)hipStreamDestroy(h->st_roll);
   delete h;
 }
 
@@ -2064,7 +2091,10 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
                           int i0 = 0, int i1 = -1) {
   if (i1 < 0) i1 = P.N;
   Timed t(h, st, 1);
-  dim3 grid((P.Bp * 4 + 63) / 64), blk(64);  // four lanes per trajectory
+  // four lanes per trajectory; 64-thread groups so that the 256 waves of a 4096-batch land on 256
+  // different CUs: the sweep streams ~16 KB per wave-step from HBM and one CU sustains ~10 B/cycle of
+  // misses (4 waves on one CU: 0.96 ms instead of 0.47, SQ_VMEM_TA_*_FIFO_FULL x7)
+  dim3 grid((P.Bp * 4 + 63) / 64), blk(64);
   if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha, i0, i1);
   else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha, i0, i1);
   else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha, i0, i1);
@@ -2097,13 +2127,18 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
     if (!opt->line_search && h->st2 && P.N >= 8) {
-      // accept-always rollout: issue it in NSEG segments on the caller's stream and re-linearise every
-      // finished segment on the library's second stream meanwhile (K3 keeps 64 waves busy, K1 the rest)
+      // accept-always rollout: issue it in NSEG segments and re-linearise every finished segment on
+      // the library's second stream meanwhile (disjoint CU masks, see tolg_create)
       const int NSEG = 4;
+      hipStream_t sr = h->st_roll ? h->st_roll : st;
+      if (h->st_roll) {
+        if (hipEventRecord(h->seg_ev[NSEG + 1], st) != hipSuccess) return TOLG_E_LAUNCH;
+        if (hipStreamWaitEvent(sr, h->seg_ev[NSEG + 1], 0) != hipSuccess) return TOLG_E_LAUNCH;
+      }
       for (int sg = 0; sg < NSEG; sg++) {
         const int i0 = (int)((long)P.N * sg / NSEG), i1 = (int)((long)P.N * (sg + 1) / NSEG);
-        if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear, 1, i0, i1))) return rc;
-        if (hipEventRecord(h->seg_ev[sg], st) != hipSuccess) return TOLG_E_LAUNCH;
+        if ((rc = run_rollout_ms<M>(h, P, sr, 1.0, opt->rollout_linear, 1, i0, i1))) return rc;
+        if (hipEventRecord(h->seg_ev[sg], sr) != hipSuccess) return TOLG_E_LAUNCH;
         if (hipStreamWaitEvent(h->st2, h->seg_ev[sg], 0) != hipSuccess) return TOLG_E_LAUNCH;
         const int k1 = (sg == NSEG - 1) ? P.N + 1 : i1;  // the last segment also takes the terminal knot
         if ((rc = run_linearize<M>(h, P, h->st2, P.cand, P.cand_u, P.cur, P.cur_u, 1, i0, k1 - i0))) return rc;
