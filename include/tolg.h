@@ -31,7 +31,10 @@ extern "C" {
  * u[3:6] = 0, J = blkdiag(J_so3, I3), R = blkdiag(R_so3, I3), Q/P with zero rows for the unused
  * coordinates.  The rotational sub-problem decouples exactly; Jacobian and cost follow the SO3
  * classes (no swapped-twist quirk, terminal l and l_x weighted with Q). */
-enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3 };
+/* TOLG_DYN_PENDULUM3D: Pendulum3dDyanmics (traoptlibrary/traopt_dynamics.py:421-626) under the SO3 cost and
+ * controllers, same embedding as TOLG_DYN_SO3; the pivot acceleration u in R^3 is u[0:3].  Its F_u
+ * depends on the state (J^-1 skew(m rho) R^T dt), the lower-left block of F_x on the input. */
+enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3, TOLG_DYN_PENDULUM3D = 4 };
 enum { TOLG_MODE_MS = 0, TOLG_MODE_SS = 1 };
 enum { TOLG_E_ARG = -1, TOLG_E_WORKSPACE = -2, TOLG_E_LAUNCH = -3, TOLG_E_SINGULAR = -4 };
 enum { TOLG_ST_OK = 0, TOLG_ST_MAXREG = 1, TOLG_ST_NODESCENT = 2, TOLG_ST_NONFINITE = 3 };
@@ -51,6 +54,8 @@ typedef struct {
                      traopt_cost.py:697,702) */
   double P[144];  /* terminal weights */
   double R[36];   /* m x m row-major */
+  double pend_mass;   /* Pendulum3dDyanmics m      (traopt_dynamics.py:425; other kinds: ignored) */
+  double pend_length; /* Pendulum3dDyanmics length (traopt_dynamics.py:425) */
 } tolg_problem;
 
 /* Replaces the keyword arguments of iLQR_Tracking_SE3_MS.__init__/fit and

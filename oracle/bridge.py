@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtolg_oracle.so")
 
-DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3 = 0, 1, 2, 3
+DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3, DYN_PENDULUM3D = 0, 1, 2, 3, 4
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -23,6 +23,7 @@ class Problem(C.Structure):
         ("J", C.c_double * 36), ("Q", C.c_double * 144), ("P", C.c_double * 144), ("R", C.c_double * 36),
         ("q_ref", _dp), ("xi_ref", _dp),
         ("al_on", C.c_int), ("al_lb", _dp), ("al_ub", _dp), ("al_lambda", _dp), ("al_imu", _dp),
+        ("pend_mass", C.c_double), ("pend_length", C.c_double),
     ]
 
 
@@ -67,8 +68,9 @@ def _c(a, shape=None):
 class OracleProblem:
     """Holds a Problem struct plus the numpy arrays it points into."""
 
-    def __init__(self, kind, J, dt, Q, R, P, q_ref, xi_ref, al=None):
-        kind = {"se3": DYN_SE3, "rigidbody": DYN_RIGIDBODY, "drone": DYN_DRONE, "so3": DYN_SO3}.get(kind, kind)
+    def __init__(self, kind, J, dt, Q, R, P, q_ref, xi_ref, al=None, pend_mass=0.0, pend_length=0.0):
+        kind = {"se3": DYN_SE3, "rigidbody": DYN_RIGIDBODY, "drone": DYN_DRONE, "so3": DYN_SO3,
+                "pendulum3d": DYN_PENDULUM3D}.get(kind, kind)
         self.m = 4 if kind == DYN_DRONE else 6
         self.N = int(q_ref.shape[0]) - 1
         self.q_ref = _c(q_ref, (self.N + 1, 16))
@@ -82,6 +84,7 @@ class OracleProblem:
         Rm[: self.m * self.m] = _c(R).reshape(-1)
         p.R[:] = list(Rm)
         p.q_ref, p.xi_ref = _p(self.q_ref), _p(self.xi_ref)
+        p.pend_mass, p.pend_length = float(pend_mass), float(pend_length)
         p.al_on = 0
         if al is not None:
             self.al = [_c(al["lb"]), _c(al["ub"]), _c(al["lam"], (self.N, 2 * self.m)), _c(al["imu"], (self.N, 2 * self.m))]
@@ -184,9 +187,10 @@ def f(prob, q, xi, u):
     return qn, xin
 
 
-def fx_fu(prob, q, xi):
+def fx_fu(prob, q, xi, u=None):
     q = _c(q); xi = _c(xi); Fx = np.zeros((12, 12)); Fu = np.zeros((12, prob.m))
-    lib().tolg_oracle_fx_fu(C.byref(prob.c), _p(q), _p(xi), _p(Fx), _p(Fu))
+    u = _c(u if u is not None else np.zeros(prob.m))
+    lib().tolg_oracle_fx_fu(C.byref(prob.c), _p(q), _p(xi), _p(u), _p(Fx), _p(Fu))
     return Fx, Fu
 
 
@@ -197,6 +201,14 @@ def cost(prob, q, xi, u, i, terminal=False):
     lib().tolg_oracle_cost(C.byref(prob.c), _p(q), _p(xi), _p(u), int(i), int(terminal), C.byref(l), _p(lx), _p(lxx),
                            _p(lu), _p(luu))
     return l.value, lx, lxx, lu, luu
+
+
+def embed_pendulum_problem(J3, mass, length, dt, Q6, R3, P6, R_ref, w_ref):
+    """Pendulum3dDyanmics + SO3 tracking cost in the SE(3) containers (TOLG_DYN_PENDULUM3D)."""
+    o = embed_so3_problem(J3, dt, Q6, R3, P6, R_ref, w_ref)
+    o.c.kind = DYN_PENDULUM3D
+    o.c.pend_mass, o.c.pend_length = float(mass), float(length)
+    return o
 
 
 def embed_so3_problem(J3, dt, Q6, R3, P6, R_ref, w_ref):

@@ -342,7 +342,13 @@ static void coad6(const double xi[6], double A[36]) {
  * (J = blkdiag(J_so3, I3)): the rotational sub-problem decouples exactly, so costs, gradients, defects
  * and iterates are those of the SO(3) solver.  Pinned against the reference's SO3 run in
  * tests/golden/so3_n249_log.json. */
-enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3 };
+/* TOLG_DYN_PENDULUM3D: Pendulum3dDyanmics (traopt_dynamics.py:421-626) with the SO3 tracking cost and the
+ * SO3 controllers, in the same embedding as TOLG_DYN_SO3; the pivot acceleration u in R^3 rides in
+ * u[0:3].  pend_mass / pend_length are the constructor's m and length.  No artefact of the reference
+ * pins this model (its only golden is a pickle no safe loader reads): parity unpinned, checked by
+ * finite differences and the closed forms in tests/test_pendulum.py. */
+enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3, TOLG_DYN_PENDULUM3D = 4 };
+#define IS_SO3(k) ((k) == TOLG_DYN_SO3 || (k) == TOLG_DYN_PENDULUM3D)
 
 typedef struct {
   int kind;          /* SE3Dynamics / RigidBodyDynamics / DroneDynamics */
@@ -360,6 +366,7 @@ typedef struct {
   const double *al_lb, *al_ub; /* m */
   const double *al_lambda;     /* N x 2m */
   const double *al_imu;        /* N x 2m (diagonal of I_mu) */
+  double pend_mass, pend_length; /* Pendulum3dDyanmics m, length (other kinds: ignored) */
 } tolg_problem;
 
 typedef struct {
@@ -396,7 +403,7 @@ static int dyn_init(const tolg_problem *p, dyn_cache *c) {
   if (inv6(p->J, c->Jinv)) return -1;
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c->Ib[3 * i + j] = p->J[6 * i + j];
   c->mass = p->J[6 * 4 + 4];
-  c->grav = (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;
+  c->grav = (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_SO3) ? 0.0 : 9.8; /* :1245, pendulum :466 */
   memset(c->Pu, 0, sizeof c->Pu);
   if (p->kind == TOLG_DYN_DRONE) {
     if (m != 4) return -2;
@@ -404,6 +411,8 @@ static int dyn_init(const tolg_problem *p, dyn_cache *c) {
   } else {
     if (m != 6) return -2;
     for (int i = 0; i < 6; i++) c->Pu[i * 6 + i] = 1;
+    /* the pendulum's input acts through skew(m rho) R^T u only (traopt_dynamics.py:539-540) */
+    if (p->kind == TOLG_DYN_PENDULUM3D) for (int i = 0; i < 3; i++) c->Pu[i * 6 + i] = 0;
   }
   memset(c->Bt, 0, sizeof c->Bt);
   mm(6, 6, m, c->Jinv, c->Pu, c->Bt + 6 * m);
@@ -427,7 +436,22 @@ static void dyn_f(const tolg_problem *p, const dyn_cache *c, const double q[16],
   mm(6, 6, 1, p->J, xi, Jxi);
   coad6(xi, co);
   mm(6, 6, 1, co, Jxi, rhs);
-  if (c->grav != 0.0) { /* g_acc = [0; m g R^T (0,0,-1)] */
+  if (p->kind == TOLG_DYN_PENDULUM3D) {
+    /* Pendulum3dDyanmics.fd_euler (traopt_dynamics.py:531-552): rho = l/2 (0,0,-1),
+     * g_term = skew(m g rho) R^T (0,0,-1), M = skew(m rho) R^T u, xi+ = xi + J^-1(ad^T J xi + g_term + M) dt */
+    double R[9], rtd[3], rtu[3], Sg[9], Sm[9], gt[3], Mt[3];
+    const double rho[3] = {0, 0, -p->pend_length / 2};
+    double mgr[3], mr[3];
+    for (int i = 0; i < 3; i++) { mgr[i] = p->pend_mass * c->grav * rho[i]; mr[i] = p->pend_mass * rho[i]; }
+    rotm_from_quat(X.q, R);
+    for (int i = 0; i < 3; i++) {
+      rtd[i] = -R[3 * 2 + i];
+      rtu[i] = R[3 * 0 + i] * u[0] + R[3 * 1 + i] * u[1] + R[3 * 2 + i] * u[2];
+    }
+    skew3(mgr, Sg); skew3(mr, Sm);
+    mat3_vec(Sg, rtd, gt); mat3_vec(Sm, rtu, Mt);
+    for (int i = 0; i < 3; i++) rhs[i] = rhs[i] + gt[i] + Mt[i];
+  } else if (c->grav != 0.0) { /* g_acc = [0; m g R^T (0,0,-1)] */
     double R[9];
     rotm_from_quat(X.q, R);
     for (int i = 0; i < 3; i++) rhs[3 + i] += c->mass * c->grav * (-R[3 * 2 + i]);
@@ -442,7 +466,7 @@ static void dyn_f(const tolg_problem *p, const dyn_cache *c, const double q[16],
  * RigidBodyDynamics (:1092-1145).  Literal quirks kept: coadjoint of the manif-ordered twist
  * [v, w] (:832, :1464); gravity Jacobian without m*g (:1445-1458). */
 static void dyn_fx(const tolg_problem *p, const dyn_cache *c, const double q[16], const double xi[6],
-                   double Fx[144]) {
+                   const double *u, double Fx[144]) {
   se3_t X, E, Ei;
   double tau[6], Jqq[36], Jqxi[36];
   se3_from_matrix(q, &X);
@@ -464,8 +488,8 @@ static void dyn_fx(const tolg_problem *p, const dyn_cache *c, const double q[16]
     }
   double sw[6] = {xi[3], xi[4], xi[5], xi[0], xi[1], xi[2]}; /* manif coeffs [v, w] */
   double co[36], coJ[36], H[36];
-  if (p->kind == TOLG_DYN_SO3) {
-    /* SO3Dynamics.f_x (traopt_dynamics.py:385-400): G = skew(J w), H = J^-1 (smallAdj(w)^T J + G) with
+  if (IS_SO3(p->kind)) {
+    /* SO3Dynamics.f_x (the pendulum's H is the same expression, :566-567) (traopt_dynamics.py:385-400): G = skew(J w), H = J^-1 (smallAdj(w)^T J + G) with
      * smallAdj(w) = skew(w) -- no swapped-twist quirk on SO(3); the unused v block stays the identity */
     double Sw[9], JJ[9], Ji3[9], T3[9], H3[9];
     skew3(xi, Sw);
@@ -485,7 +509,24 @@ static void dyn_fx(const tolg_problem *p, const dyn_cache *c, const double q[16]
   }
   double L[36];
   memset(L, 0, sizeof L);
-  if (c->grav != 0.0) { /* J_v_R = skew(R^T (0,0,-1)) */
+  if (p->kind == TOLG_DYN_PENDULUM3D) {
+    /* Pendulum3dDyanmics.f_x (traopt_dynamics.py:574-588): manif gives J_inv = -Ad(q) = -R and, for
+     * q^-1.act(v), J_wrt_q^-1 = -R^T skew(v), so J_act J_inv = R^T skew(v) R;
+     * L1 = skew(m g rho) J J_inv (v = down), L2 = skew(m rho) J J_inv (v = u), L = J^-1 (L1 + L2) */
+    double R[9], Rt[9], Sv[9], T1[9], JJ[9], Sg[9], Sm[9], L1[9], L2[9], Ji3[9], L3[9];
+    const double down[3] = {0, 0, -1.0};
+    const double rho[3] = {0, 0, -p->pend_length / 2};
+    double mgr[3], mr[3], uu[3] = {u ? u[0] : 0.0, u ? u[1] : 0.0, u ? u[2] : 0.0};
+    for (int i = 0; i < 3; i++) { mgr[i] = p->pend_mass * c->grav * rho[i]; mr[i] = p->pend_mass * rho[i]; }
+    rotm_from_quat(X.q, R); mat3_T(R, Rt);
+    skew3(mgr, Sg); skew3(mr, Sm);
+    skew3(down, Sv); mat3_mul(Rt, Sv, T1); mat3_mul(T1, R, JJ); mat3_mul(Sg, JJ, L1);
+    skew3(uu, Sv); mat3_mul(Rt, Sv, T1); mat3_mul(T1, R, JJ); mat3_mul(Sm, JJ, L2);
+    for (int i = 0; i < 9; i++) L1[i] += L2[i];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ji3[3 * i + j] = c->Jinv[6 * i + j];
+    mat3_mul(Ji3, L1, L3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[6 * i + j] = L3[3 * i + j] * p->dt;
+  } else if (c->grav != 0.0) { /* J_v_R = skew(R^T (0,0,-1)) */
     double R[9], rte[3], S[9], Jxiq[36];
     rotm_from_quat(X.q, R);
     for (int i = 0; i < 3; i++) rte[i] = -R[3 * 2 + i];
@@ -504,8 +545,21 @@ static void dyn_fx(const tolg_problem *p, const dyn_cache *c, const double q[16]
     }
 }
 /* f_u = Bt * dt (traopt_dynamics.py:839-850, :1471-1482) */
-static void dyn_fu(const tolg_problem *p, const dyn_cache *c, double Fu[72]) {
+static void dyn_fu(const tolg_problem *p, const dyn_cache *c, const double q[16], double Fu[72]) {
   for (int i = 0; i < 12 * p->m; i++) Fu[i] = c->Bt[i] * p->dt;
+  if (p->kind == TOLG_DYN_PENDULUM3D) {
+    /* Pendulum3dDyanmics.f_u (traopt_dynamics.py:596-609): bt = J^-1 skew(m rho) J_act_wrt_v with
+     * J_act_wrt_v = R^T (the rotation of q^-1); state dependent */
+    se3_t X;
+    double R[9], Rt[9], Sm[9], T1[9], Ji3[9], bt[9];
+    const double mr[3] = {0, 0, -p->pend_mass * p->pend_length / 2};
+    se3_from_matrix(q, &X);
+    rotm_from_quat(X.q, R); mat3_T(R, Rt);
+    skew3(mr, Sm); mat3_mul(Sm, Rt, T1);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ji3[3 * i + j] = c->Jinv[6 * i + j];
+    mat3_mul(Ji3, T1, bt);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Fu[(6 + i) * p->m + j] = bt[3 * i + j] * p->dt;
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -532,7 +586,7 @@ static double cost_l(const tolg_problem *p, const dyn_cache *c, const double q[1
   se3_t X;
   double e[6], ve[6], s = 0;
   /* SO3 cost: _l_terminal weighs with Q, not P (traopt_cost.py:434-438) */
-  const double *W = (terminal && p->kind != TOLG_DYN_SO3) ? p->P : p->Q;
+  const double *W = (terminal && !IS_SO3(p->kind)) ? p->P : p->Q;
   se3_from_matrix(q, &X);
   se3_lminus(&X, &c->qref[i], e, NULL);
   for (int a = 0; a < 6; a++) ve[a] = xi[a] - p->xi_ref[6 * i + a];
@@ -554,7 +608,7 @@ static void cost_lx_lxx(const tolg_problem *p, const dyn_cache *c, const double 
   double e[6], Je[36], W1[36], WJ[36], We[6];
   const double *W = terminal ? p->P : p->Q;
   /* SO3 cost: l_x always uses Q (traopt_cost.py:480-483), only l_xx switches to P (:530-531) */
-  const double *Wg = (p->kind == TOLG_DYN_SO3) ? p->Q : W;
+  const double *Wg = (IS_SO3(p->kind)) ? p->Q : W;
   se3_from_matrix(q, &X);
   se3_lminus(&X, &c->qref[i], e, Je);
   for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) W1[6 * a + b] = Wg[12 * a + b];
@@ -689,8 +743,8 @@ static void linearize(const tolg_problem *p, const dyn_cache *c, ws_t *w, int ms
     const double *q = w->xq + 16 * i, *xi = w->xxi + 6 * i, *u = w->us + m * i;
     if (ms) defect_knot(p, c, q, xi, u, w->xq + 16 * (i + 1), w->xxi + 6 * (i + 1), w->d + 12 * i);
     else memset(w->d + 12 * i, 0, 12 * sizeof(double));
-    dyn_fx(p, c, q, xi, w->Fx + 144 * i);
-    dyn_fu(p, c, w->Fu + 12 * m * i);
+    dyn_fx(p, c, q, xi, u, w->Fx + 144 * i);
+    dyn_fu(p, c, q, w->Fu + 12 * m * i);
     w->L[i] = cost_l(p, c, q, xi, u, i, 0);
     cost_lx_lxx(p, c, q, xi, i, 0, w->Lx + 12 * i, w->Lxx + 144 * i);
     cost_lu_luu(p, u, i, w->Lu + m * i, w->Luu + m * m * i);
@@ -1001,11 +1055,11 @@ int tolg_oracle_ms_fit(const tolg_problem *p, const tolg_options *o, const doubl
       rollout_ms(p, &c, &w, 1.0, 1); /* rollout="linear" (:2550) */
       expected_cost_change(p, &w, ecc);
       double d_weight;
-      if (dn < ((p->kind == TOLG_DYN_SO3) ? 1e-14 : 1e-12)) d_weight = d_weight_prev; /* _defect_kappa (:2777, SO3 :1090) */
+      if (dn < ((IS_SO3(p->kind)) ? 1e-14 : 1e-12)) d_weight = d_weight_prev; /* _defect_kappa (:2777, SO3 :1090) */
       else d_weight = fmax(10.0, 10.0 + fabs(ecc[0] + 0.5 * ecc[1]) / ((1 - 0.5) * dn));
       d_weight_prev = d_weight;
       double merit = J_opt + d_weight * dn;
-      for (int a = 0; a < ((p->kind == TOLG_DYN_SO3) ? SS_ALPHAS : MS_ALPHAS); a++) { /* SO3 MS: 13 alphas (:1160) */
+      for (int a = 0; a < ((IS_SO3(p->kind)) ? SS_ALPHAS : MS_ALPHAS); a++) { /* SO3 MS: 13 alphas (:1160) */
         alpha = pow(1.1, -(double)(a * a));
         rollout_ms(p, &c, &w, alpha, o->rollout_linear);
         J_new = traj_cost(p, &c, w.nq, w.nxi, w.nus);
@@ -1149,9 +1203,10 @@ int tolg_oracle_f(const tolg_problem *p, const double q[16], const double xi[6],
   dyn_cache c; int rc = dyn_init(p, &c); if (rc) return rc;
   dyn_f(p, &c, q, xi, u, qn, xin); dyn_free(&c); return 0;
 }
-int tolg_oracle_fx_fu(const tolg_problem *p, const double q[16], const double xi[6], double Fx[144], double *Fu) {
+int tolg_oracle_fx_fu(const tolg_problem *p, const double q[16], const double xi[6], const double *u, double Fx[144],
+                      double *Fu) {
   dyn_cache c; int rc = dyn_init(p, &c); if (rc) return rc;
-  dyn_fx(p, &c, q, xi, Fx); dyn_fu(p, &c, Fu); dyn_free(&c); return 0;
+  dyn_fx(p, &c, q, xi, u, Fx); dyn_fu(p, &c, q, Fu); dyn_free(&c); return 0;
 }
 int tolg_oracle_cost(const tolg_problem *p, const double q[16], const double xi[6], const double *u, int i,
                      int terminal, double *l, double lx[12], double lxx[144], double *lu, double *luu) {

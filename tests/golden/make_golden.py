@@ -240,6 +240,7 @@ def reference_trajectories():
         ("path_dense_random_columns_4obj.npy", "drone_columns_n400", 401),
         ("path_3dpendulum_8shape.npy", "so3_8shape_n249", None),
         ("path_3dpendulum_8shape_tryout.npy", "so3_8shape_tryout_n249", None),
+        ("path_3dpendulum_swingup.npy", "pendulum_swingup_n80", None),
     ]:
         q_ref, xi_ref, dt = load_traj(name)
         if n is not None:

@@ -10,7 +10,8 @@ _SO = os.path.join(_HERE, "libtolg_hip.so")
 
 
 def lib_path():
-    return _SO
+    """The in-tree library; TOLG_HIP_LIB points at another build of the same ABI (A/B timing runs)."""
+    return os.environ.get("TOLG_HIP_LIB") or _SO
 
 
 def _stale():

@@ -4,7 +4,7 @@ import os
 
 from ._build import lib_path
 
-DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3 = 0, 1, 2, 3
+DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3, DYN_PENDULUM3D = 0, 1, 2, 3, 4
 MODE_MS, MODE_SS = 0, 1
 ST_OK, ST_MAXREG, ST_NODESCENT, ST_NONFINITE = 0, 1, 2, 3
 _ERR = {-1: "bad argument", -2: "workspace too small", -3: "kernel launch failed", -4: "inertia matrix singular"}
@@ -13,7 +13,7 @@ _ERR = {-1: "bad argument", -2: "workspace too small", -3: "kernel launch failed
 class Problem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("m", C.c_int32), ("N", C.c_int32), ("reserved", C.c_int32),
                 ("dt", C.c_double), ("J", C.c_double * 36), ("Q", C.c_double * 144), ("P", C.c_double * 144),
-                ("R", C.c_double * 36)]
+                ("R", C.c_double * 36), ("pend_mass", C.c_double), ("pend_length", C.c_double)]
 
 
 class Options(C.Structure):

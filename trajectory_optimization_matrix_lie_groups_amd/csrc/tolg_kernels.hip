@@ -32,7 +32,7 @@ namespace tolg {
 // ------------------------------------------------------------------------------------------------
 struct Consts {
   int kind, m, N, diagJ;  // diagJ: Ib and Jv are diagonal (every reference script): 12 constants instead of 36
-  double dt, mass, grav, pad2;
+  double dt, mass, grav, pend_k;  // pend_k = m l / 2 of Pendulum3dDyanmics (0 otherwise)
   double J[36], Jinv[36], Ib[9];
   // J = blkdiag(Ib, Jv) (checked in tolg_create): the 3x3 blocks and their inverses
   double Jv[9], Ibinv[9], Jvinv[9];
@@ -125,7 +125,11 @@ enum {
   REC_A22 = 97,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
   REC_LU = 133,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
   REC_LUU = 139, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
-  REC_F = 145
+  REC_F = 145,
+  // Pendulum3dDyanmics only: F_u[6:9,0:3] = J^-1 skew(m rho) R^T dt (state dependent), row-major, in the
+  // slot of REC_TRI -- that block of F_x is identically zero without a translation, and an extra
+  // field would leave a never-written hole in every 4.6 KB record group of all the other models
+  REC_BU = REC_TRI
 };
 // Records and gains are interleaved by four trajectories: [knot][b / 4][field][b % 4].  The four
 // trajectories of one K2 wavefront then own one contiguous 4.6 KB run per knot (every 64-byte
@@ -138,6 +142,8 @@ enum {
 #define REC_SR 32u
 #define REC_VR(b) ((unsigned)((b) >> 2) * (REC_F * 32u) + (unsigned)((b) & 3) * 8u)
 #define GK_VG(b, M_) ((unsigned)((b) >> 2) * (13u * (M_) * 32u) + (unsigned)((b) & 3) * 8u)
+// SO3Dynamics and Pendulum3dDyanmics share the SO3 cost / controller conventions
+__host__ __device__ inline bool so3_family(int kind) { return kind == TOLG_DYN_SO3 || kind == TOLG_DYN_PENDULUM3D; }
 __host__ __device__ inline int sym6(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,7 +194,9 @@ TOLG_DEV double fu_entry(const CT& C, int r, int u) {
   if (r < 3) return (u < 3) ? C.Bt[3 * r + u] : 0.0;
   return (u >= 3) ? C.Bb[3 * (r - 3) + (u - 3)] : 0.0;
 }
-template <int M, class CT>
+// PK: 0 the model is never the pendulum, 1 always, 2 decided at run time (kernel-uniform).  The sequential
+// rollout instantiates 0 / 1 separately: even an untaken uniform branch costs its schedule 2-3 %.
+template <int M, class CT, int PK = 2>
 TOLG_DEV State dyn_f(const CT& C, const State& S, const double (&u)[M]) {
   State F;
   const double dt = C.dt;
@@ -206,9 +214,16 @@ TOLG_DEV State dyn_f(const CT& C, const State& S, const double (&u)[M]) {
   }
   V3 top = cross(y1, S.w) + cross(y2, S.v);  // ad(xi)^T (J xi), upper half
   V3 bot = cross(y2, S.w);
-  if (C.grav != 0.0) bot = bot + (C.mass * C.grav) * qrot_inv(S.X.q, v3(0, 0, -1.0));
-  // Pu u: identity (SE3 / RigidBody) or the drone selector (u0..2 -> torque, u3 -> f_z)
-  top = top + v3(u[0], u[1], u[2]);
+  if (PK == 1 || (PK == 2 && C.kind == TOLG_DYN_PENDULUM3D)) {
+    // Pendulum3dDyanmics.fd_euler (traopt_dynamics.py:531-552): g_term + M =
+    // skew(m rho) R^T (g (0,0,-1) + u) with rho = l/2 (0,0,-1), i.e. k (w_y, -w_x, 0), k = m l / 2
+    V3 wv = qrot_inv(S.X.q, v3(u[0], u[1], u[2] - C.grav));
+    top = top + v3(C.pend_k * wv.y, -C.pend_k * wv.x, 0.0);
+  } else {
+    if (C.grav != 0.0) bot = bot + (C.mass * C.grav) * qrot_inv(S.X.q, v3(0, 0, -1.0));
+    // Pu u: identity (SE3 / RigidBody) or the drone selector (u0..2 -> torque, u3 -> f_z)
+    top = top + v3(u[0], u[1], u[2]);
+  }
   if constexpr (M == 6) bot = bot + v3(u[3], u[4], u[5]);
   else bot = bot + v3(0, 0, u[3]);
   if (dj) {
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
     // weights: l_xx switches to P at the terminal knot; l and l_x too, except for the SO3 cost which
     // keeps Q there (traopt_cost.py:434-438, :480-483 vs :530-531)
-    const bool so3 = C.kind == TOLG_DYN_SO3;
+    const bool so3 = so3_family(C.kind);
     const double* W1 = term ? C.P1 : C.W1;
     const double* W2 = term ? C.P2 : C.W2;
     const double* G1 = (term && !so3) ? C.P1 : C.W1;
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         P.REC[RIDX(i, REC_RI + 3 * c + a, b)] = Ri[3 * a + c];
-        P.REC[RIDX(i, REC_TRI + 3 * c + a, b)] = TR[3 * a + c];
+        if (C.kind != TOLG_DYN_PENDULUM3D) P.REC[RIDX(i, REC_TRI + 3 * c + a, b)] = TR[3 * a + c];  // else: REC_BU
         P.REC[RIDX(i, REC_JR + 3 * c + a, b)] = dt * Jr3[3 * a + c];
         P.REC[RIDX(i, REC_QR + 3 * c + a, b)] = dt * Qr[3 * a + c];
       }
@@ -522,8 +537,8 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     mul33(Sv, C.Jv, T1);
 #pragma unroll
     for (int k = 0; k < 9; k++) M22[k] = -T1[k];
-    if (C.kind == TOLG_DYN_SO3) {
-      // SO3Dynamics.f_x (traopt_dynamics.py:385-400): H = J^-1 (skew(w)^T J + skew(J w)) -- the SO(3)
+    if (so3_family(C.kind)) {
+      // SO3Dynamics.f_x (and Pendulum3dDyanmics.f_x :566-567) (traopt_dynamics.py:385-400): H = J^-1 (skew(w)^T J + skew(J w)) -- the SO(3)
       // model has no swapped-twist quirk; the unused linear-velocity block is the identity
       mul33(Sw, C.Ib, T1);
 #pragma unroll
@@ -547,6 +562,23 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   }
   {
     V3 rte = (C.grav != 0.0) ? qrot_inv(S.X.q, v3(0, 0, -1.0)) : v3(0, 0, 0);
+    if (C.kind == TOLG_DYN_PENDULUM3D) {
+      // Pendulum3dDyanmics.f_x / f_u (traopt_dynamics.py:574-609).  L1 + L2 = skew(m rho) skew(w) with
+      // w = R^T (g (0,0,-1) + u): the lower-left block stays linear in one body-frame vector, which takes
+      // the place of R^T e3 here; F_u = J^-1 skew(m rho) R^T dt goes to REC_BU.
+      rte = qrot_inv(S.X.q, v3(u[0], u[1], u[2] - C.grav));
+      double Rm[9], SR[9], Bu[9];
+      q_to_R(S.X.q, Rm);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {  // skew(m rho) R^T = k [row 1 of R^T; -row 0 of R^T; 0]
+        SR[c] = C.pend_k * Rm[3 * c + 1];
+        SR[3 + c] = -C.pend_k * Rm[3 * c + 0];
+        SR[6 + c] = 0.0;
+      }
+      mul33(C.Ibinv, SR, Bu);
+#pragma unroll
+      for (int k = 0; k < 9; k++) P.REC[RIDX(i, REC_BU + k, b)] = dt * Bu[k];
+    }
     P.REC[RIDX(i, REC_RTE + 0, b)] = rte.x;
     P.REC[RIDX(i, REC_RTE + 1, b)] = rte.y;
     P.REC[RIDX(i, REC_RTE + 2, b)] = rte.z;
@@ -842,7 +874,8 @@ TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
   }
 }
 
-template <int M>
+// VARB: F_u differs from knot to knot (Pendulum3dDyanmics): its 3x3 block is read from REC_BU
+template <int M, bool VARB = false>
 __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
@@ -870,7 +903,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
   int fT = REC_D, fM = REC_D + 3;
   double mT = 0.0, mM = 0.0;
-  if (j < 3) { fT = REC_RI + 3 * j; fM = REC_TRI + 3 * j; mT = 1; mM = 1; }
+  if (j < 3) { fT = REC_RI + 3 * j; fM = REC_TRI + 3 * j; mT = 1; mM = VARB ? 0 : 1; }  // VARB: the slot holds REC_BU
   else if (j < 6) { fM = REC_RI + 3 * (j - 3); mM = 1; }
   else if (j < 9) { fT = REC_JR + 3 * (j - 6); fM = REC_QR + 3 * (j - 6); mT = 1; mM = 1; }
   else if (j < 12) { fM = REC_JR + 3 * (j - 9); mM = 1; }
@@ -917,7 +950,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
   // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
   // data right behind the request and undo the prefetch.
-  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M], luu; };
+  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M], luu, bu[VARB ? 9 : 1]; };
   auto load_knot = [&](int i, BwdIn& in) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
 #pragma unroll
@@ -939,6 +972,10 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
     for (int a = 0; a < M; a++) in.lu[a] = bld(rR, REC_VR(b), (REC_LU + a) * REC_SR);
     in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
+    if constexpr (VARB) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) in.bu[k] = bld(rR, REC_VR(b), (REC_BU + k) * REC_SR);
+    }
   };
 
   auto step = [&](int i, BwdIn& in) {
@@ -957,6 +994,20 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r] + W2col[r]; }
 #pragma unroll
     for (int a = 0; a < M; a++) lu[a] = mvec * in.lu[a];  // l_u = 2 R u rides in the vector columns
+    // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
+    double BtS[VARB ? 9 : 1], BlocS[VARB ? 6 : 1], BrowS[VARB ? M : 1];
+    if constexpr (VARB) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) BtS[k] = in.bu[k];
+#pragma unroll
+      for (int r = 0; r < 6; r++) BlocS[r] = Bloc[r];
+#pragma unroll
+      for (int u = 0; u < M; u++) BrowS[u] = Brow[u];
+#pragma unroll
+      for (int r = 0; r < 3; r++) BlocS[r] = (j == 0) ? BtS[3 * r] : (j == 1) ? BtS[3 * r + 1] : (j == 2) ? BtS[3 * r + 2] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 3; u++) BrowS[u] = (j == 6) ? BtS[u] : (j == 7) ? BtS[3 + u] : (j == 8) ? BtS[6 + u] : 0.0;
+    }
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
 #pragma unroll
@@ -1012,11 +1063,11 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         double T[M];
 #pragma unroll
         for (int u = 0; u < M; u++) {  // B2 is block diagonal: inputs 0..2 see rows 6..8, the rest rows 9..11
-          double s = lu[u], tt = muA * Brow[u];
+          double s = lu[u], tt = muA * (VARB ? BrowS[VARB ? u : 0] : Brow[u]);
           const int k0 = (u < 3) ? 0 : 3;
 #pragma unroll
           for (int k = 0; k < 3; k++) {
-            const double bku = (u < 3) ? C.Bt[3 * k + u] : C.Bb[3 * k + (u - 3)];
+            const double bku = (u < 3) ? (VARB ? BtS[VARB ? 3 * k + u : 0] : C.Bt[3 * k + u]) : C.Bb[3 * k + (u - 3)];
             s += bku * Xp[k0 + k];
             tt += bku * V[6 + k0 + k];
           }
@@ -1027,8 +1078,14 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         double Quu[M];
 #pragma unroll
         for (int u = 0; u < M; u++) Quu[u] = Rcol[u] + ((j == u) ? luu_i : 0.0);
-        quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
-        quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
+        if constexpr (VARB) {
+          quu_acc<M, 6>(Quu, T, BlocS[0]); quu_acc<M, 7>(Quu, T, BlocS[1]); quu_acc<M, 8>(Quu, T, BlocS[2]);
+          quu_acc<M, 9>(Quu, T, BlocS[3 % (VARB ? 6 : 1)]); quu_acc<M, 10>(Quu, T, BlocS[4 % (VARB ? 6 : 1)]);
+          quu_acc<M, 11>(Quu, T, BlocS[5 % (VARB ? 6 : 1)]);
+        } else {
+          quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
+          quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
+        }
         // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
         // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
 #pragma unroll
@@ -1147,7 +1204,8 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
   double Ri[9], TRi[9], Jr[9], Qr[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
-    Ri[k] = P.REC[RIDX(i, REC_RI + k, b)]; TRi[k] = P.REC[RIDX(i, REC_TRI + k, b)];
+    Ri[k] = P.REC[RIDX(i, REC_RI + k, b)];
+    TRi[k] = (C.kind == TOLG_DYN_PENDULUM3D) ? 0.0 : P.REC[RIDX(i, REC_TRI + k, b)];  // pendulum: the slot is REC_BU
     Jr[k] = P.REC[RIDX(i, REC_JR + k, b)]; Qr[k] = P.REC[RIDX(i, REC_QR + k, b)];
   }
 #pragma unroll
@@ -1173,7 +1231,11 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
       sacc += l * e[c];
     }
 #pragma unroll
-    for (int k = 0; k < M; k++) sacc += fu_entry<M>(C, r, k) * du[k];
+    for (int k = 0; k < M; k++) {
+      double fu = fu_entry<M>(C, r, k);
+      if (C.kind == TOLG_DYN_PENDULUM3D && r < 3 && k < 3) fu = P.REC[RIDX(i, REC_BU + 3 * r + k, b)];
+      sacc += fu * du[k];
+    }
     lin[6 + r] = sacc;
   }
 }
@@ -1221,7 +1283,7 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
   }
 }
 
-template <int M, bool LINEAR, bool ALPHA1, class CT>
+template <int M, bool LINEAR, bool ALPHA1, int PK, class CT>
 TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool writer, unsigned vb, unsigned sB,
                          double alpha, const State& So, const State& Sn) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
@@ -1250,7 +1312,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool
   for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
   State Nx;
   if constexpr (!LINEAR) {
-    State Fn = dyn_f<M>(C, Sn, un);
+    State Fn = dyn_f<M, CT, PK>(C, Sn, un);
     Pose Mx;
     V3 cw, cv;
     if constexpr (ALPHA1) {
@@ -1261,7 +1323,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool
       double d[12];
 #pragma unroll
       for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
-      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, R.u);
+      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M, CT, PK>(C, So, R.u);
       Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                        se3_inverse(Fo.X));
       cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
@@ -1291,7 +1353,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool
   return Nx;
 }
 
-template <int M, bool LINEAR, bool ALPHA1>
+template <int M, bool LINEAR, bool ALPHA1, int PK = 0>
 __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
@@ -1317,11 +1379,11 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i, b, q, writer, vb, sB, alpha, Sa, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, i, b, q, writer, vb, sB, alpha, Sa, Sn);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1>(P, C, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
   }
 }
 
@@ -1343,7 +1405,7 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
   Xr.t = v3(r[4], r[5], r[6]);
   V3 ew, ev;
   se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
-  const bool so3 = C.kind == TOLG_DYN_SO3;  // the SO3 terminal cost is weighted with Q (App. C-Q3)
+  const bool so3 = so3_family(C.kind);  // the SO3 terminal cost is weighted with Q (App. C-Q3)
   const double* W1 = (term && !so3) ? C.P1 : C.W1;
   const double* W2 = (term && !so3) ? C.P2 : C.W2;
   double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
@@ -1525,7 +1587,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   P.ecc[2 * b] = c1;
   P.ecc[2 * b + 1] = c2;
   double dn = P.dn[b], wprev = P.dweight[2 * b + 1], w;
-  if (dn < ((C.kind == TOLG_DYN_SO3) ? 1e-14 : 1e-12)) w = wprev;  // _defect_kappa (SE3 :2410, SO3 :1090)
+  if (dn < ((so3_family(C.kind)) ? 1e-14 : 1e-12)) w = wprev;  // _defect_kappa (SE3 :2410, SO3 :1090)
   else w = fmax(10.0, 10.0 + fabs(c1 + 0.5 * c2) / ((1.0 - 0.5) * dn));
   P.dweight[2 * b] = w;
   P.dweight[2 * b + 1] = w;
@@ -1684,7 +1746,8 @@ __global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double
     for (int k = 0; k < 12 * m; k++) F[k] = 0;
     for (int r = 0; r < 6; r++)
       for (int k = 0; k < m; k++)
-        F[(6 + r) * m + k] = (r < 3) ? (k < 3 ? C.Bt[3 * r + k] : 0.0) : (k >= 3 ? C.Bb[3 * (r - 3) + (k - 3)] : 0.0);
+        F[(6 + r) * m + k] = (r < 3) ? (k < 3 ? (C.kind == TOLG_DYN_PENDULUM3D ? P.REC[RIDX(i, REC_BU + 3 * r + k, b)] : C.Bt[3 * r + k]) : 0.0)
+                                     : (k >= 3 ? C.Bb[3 * (r - 3) + (k - 3)] : 0.0);
   }
   if (Fx) {
     double* F = Fx + (size_t)b * 144;
@@ -1693,7 +1756,7 @@ __global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double
       for (int c = 0; c < 3; c++) {
         double ri = P.REC[RIDX(i, REC_RI + 3 * c + r, b)], jr = P.REC[RIDX(i, REC_JR + 3 * c + r, b)];
         F[12 * r + c] = ri; F[12 * (r + 3) + c + 3] = ri;
-        F[12 * (r + 3) + c] = P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
+        F[12 * (r + 3) + c] = (C.kind == TOLG_DYN_PENDULUM3D) ? 0.0 : P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
         F[12 * r + c + 6] = jr; F[12 * (r + 3) + c + 9] = jr;
         F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
       }
@@ -1729,7 +1792,7 @@ __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restri
       for (int c = 0; c < 3; c++) {
         double ri = P.REC[RIDX(i, REC_RI + 3 * c + r, b)], jr = P.REC[RIDX(i, REC_JR + 3 * c + r, b)];
         F[12 * r + c] = ri; F[12 * (r + 3) + c + 3] = ri;
-        F[12 * (r + 3) + c] = P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
+        F[12 * (r + 3) + c] = (C.kind == TOLG_DYN_PENDULUM3D) ? 0.0 : P.REC[RIDX(i, REC_TRI + 3 * c + r, b)];
         F[12 * r + c + 6] = jr; F[12 * (r + 3) + c + 9] = jr;
         F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
       }
@@ -1870,7 +1933,7 @@ static int check_problem(const tolg_problem* p) {
   if (!p) return TOLG_E_ARG;
   if (p->N < 1 || !(p->dt > 0)) return TOLG_E_ARG;
   if (p->kind == TOLG_DYN_DRONE) { if (p->m != 4) return TOLG_E_ARG; }
-  else if (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_RIGIDBODY || p->kind == TOLG_DYN_SO3) { if (p->m != 6) return TOLG_E_ARG; }
+  else if (p->kind == TOLG_DYN_SE3 || p->kind == TOLG_DYN_RIGIDBODY || p->kind == TOLG_DYN_SO3 || p->kind == TOLG_DYN_PENDULUM3D) { if (p->m != 6) return TOLG_E_ARG; }
   else return TOLG_E_ARG;
   return 0;
 }
@@ -1949,7 +2012,8 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   if (host_inv6(prob->J, c.Jinv)) { delete h; return TOLG_E_SINGULAR; }
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.Ib[3 * i + j] = prob->J[6 * i + j];
   c.mass = prob->J[6 * 4 + 4];                      // traopt_dynamics.py:663
-  c.grav = (prob->kind == TOLG_DYN_SE3 || prob->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245
+  c.grav = (prob->kind == TOLG_DYN_SE3 || prob->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245, :466
+  c.pend_k = (prob->kind == TOLG_DYN_PENDULUM3D) ? prob->pend_mass * prob->pend_length / 2 : 0.0;
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++) {
       c.W1[6 * i + j] = prob->Q[12 * i + j];
@@ -1987,8 +2051,15 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
     for (int i = 0; i < 6; i++)
       for (int j = 0; j < 6; j++) {
         double sacc = 0;
-        if (j < 3 && c.grav != 0.0)
+        if (j < 3 && c.grav != 0.0 && prob->kind != TOLG_DYN_PENDULUM3D)
           for (int k = 0; k < 3; k++) sacc += c.Jinv[6 * i + 3 + k] * S[3 * k + j];
+        if (j < 3 && i < 3 && prob->kind == TOLG_DYN_PENDULUM3D) {
+          // Pendulum3dDyanmics.f_x (traopt_dynamics.py:574-588): L = J^-1 skew(m rho) skew(w), w = R^T(g e + u),
+          // skew(m rho) = k [[0,1,0],[-1,0,0],[0,0,0]]
+          const double SS[9] = {c.pend_k * S[3 + 0], c.pend_k * S[3 + 1], c.pend_k * S[3 + 2],
+                                -c.pend_k * S[0], -c.pend_k * S[1], -c.pend_k * S[2], 0, 0, 0};
+          for (int k = 0; k < 3; k++) sacc += c.Ibinv[3 * i + k] * SS[3 * k + j];
+        }
         c.Llin[a][6 * i + j] = sacc * prob->dt;
       }
   }
@@ -2082,7 +2153,10 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   Timed t(h, st, 0);
-  hipLaunchKernelGGL(k_backward<M>, dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+  if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
+    hipLaunchKernelGGL((k_backward<6, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+  else
+    hipLaunchKernelGGL(k_backward<M>, dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -2096,6 +2170,10 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
   // misses (4 waves on one CU: 0.96 ms instead of 0.47, SQ_VMEM_TA_*_FIFO_FULL x7)
   dim3 grid((P.Bp * 4 + 63) / 64), blk(64);
   if (linear) hipLaunchKernelGGL((k_rollout<M, true, false>), grid, blk, 0, st, P, alpha, i0, i1);
+  else if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
+    if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<6, false, true, 1>), grid, blk, 0, st, P, alpha, i0, i1);
+    else hipLaunchKernelGGL((k_rollout<6, false, false, 1>), grid, blk, 0, st, P, alpha, i0, i1);
+  }
   else if (alpha == 1.0 || !ms) hipLaunchKernelGGL((k_rollout<M, false, true>), grid, blk, 0, st, P, alpha, i0, i1);
   else hipLaunchKernelGGL((k_rollout<M, false, false>), grid, blk, 0, st, P, alpha, i0, i1);
   LAUNCH_CHECK();
@@ -2159,7 +2237,7 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
-      if (h->prob.kind != TOLG_DYN_SO3)  // iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20 (:2472)
+      if (!so3_family(h->prob.kind))  // iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20 (:2472)
         if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();

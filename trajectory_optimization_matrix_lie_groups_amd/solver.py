@@ -12,7 +12,8 @@ import torch
 
 from . import _capi
 
-_KIND = {"se3": _capi.DYN_SE3, "rigidbody": _capi.DYN_RIGIDBODY, "drone": _capi.DYN_DRONE, "so3": _capi.DYN_SO3}
+_KIND = {"se3": _capi.DYN_SE3, "rigidbody": _capi.DYN_RIGIDBODY, "drone": _capi.DYN_DRONE, "so3": _capi.DYN_SO3,
+         "pendulum3d": _capi.DYN_PENDULUM3D}
 
 
 @dataclass
@@ -30,6 +31,8 @@ class TrackingProblem:
     P: np.ndarray
     q_ref: np.ndarray   # (N+1, 4, 4)
     xi_ref: np.ndarray  # (N+1, 6)
+    pend_mass: float = 0.0    # Pendulum3dDyanmics m, length (traopt_dynamics.py:425); other kinds ignore them
+    pend_length: float = 0.0
 
     @property
     def N(self):
@@ -52,6 +55,14 @@ def embed_so3(J3, dt, Q6, R3, P6, R_ref, w_ref) -> TrackingProblem:
     q_ref = np.tile(np.eye(4), (n, 1, 1)); q_ref[:, :3, :3] = R_ref
     xi_ref = np.zeros((n, 6)); xi_ref[:, :3] = w_ref
     return TrackingProblem("so3", J, float(dt), Q, R, P, q_ref, xi_ref)
+
+
+def embed_pendulum3d(J3, mass, length, dt, Q6, R3, P6, R_ref, w_ref) -> TrackingProblem:
+    """Pendulum3dDyanmics (reference traoptlibrary/traopt_dynamics.py:421-626) with the SO3 tracking cost, in
+    the same embedding as embed_so3 (include/tolg.h, TOLG_DYN_PENDULUM3D); the pivot acceleration is u[0:3]."""
+    p = embed_so3(J3, dt, Q6, R3, P6, R_ref, w_ref)
+    p.kind, p.pend_mass, p.pend_length = "pendulum3d", float(mass), float(length)
+    return p
 
 
 @dataclass
@@ -90,6 +101,7 @@ class BatchedTrackingILQR:
         self.max_batch = int(max_batch)
         p = _capi.Problem()
         p.kind, p.m, p.N, p.dt = _KIND[problem.kind], self.m, self.N, float(problem.dt)
+        p.pend_mass, p.pend_length = float(problem.pend_mass), float(problem.pend_length)
         p.J[:] = list(np.asarray(problem.J, dtype=np.float64).reshape(36))
         p.Q[:] = list(np.asarray(problem.Q, dtype=np.float64).reshape(144))
         p.P[:] = list(np.asarray(problem.P, dtype=np.float64).reshape(144))

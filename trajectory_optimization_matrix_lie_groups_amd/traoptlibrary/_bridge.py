@@ -11,11 +11,11 @@ def kind_of_action_size(m):
     return "drone" if int(m) == 4 else "se3"
 
 
-def dynamics_probe(kind, J, dt):
+def dynamics_probe(kind, J, dt, pend_mass=0.0, pend_length=0.0):
     """One-knot solver used for dynamics.f / f_x / f_u (the cost terms are zero weights)."""
     m = 4 if kind == "drone" else 6
     prob = TrackingProblem(kind, np.asarray(J, float), float(dt), np.zeros((12, 12)), np.zeros((m, m)),
-                           np.zeros((12, 12)), _IDENT_REF, _ZERO_XI)
+                           np.zeros((12, 12)), _IDENT_REF, _ZERO_XI, float(pend_mass), float(pend_length))
     return BatchedTrackingILQR(prob, 1)
 
 

@@ -13,7 +13,7 @@ import numpy as np
 from ..solver import BatchedTrackingILQR, TrackingProblem
 from . import _bridge
 from .traopt_cost import ALConstrainedCost, SE3TrackingQuadraticGaussNewtonCost, SO3TrackingQuadraticGaussNewtonCost
-from .traopt_dynamics import DroneDynamics, RigidBodyDynamics, SE3Dynamics, SO3Dynamics
+from .traopt_dynamics import DroneDynamics, Pendulum3dDyanmics, RigidBodyDynamics, SE3Dynamics, SO3Dynamics
 
 _KIND = {SE3Dynamics: "se3", RigidBodyDynamics: "rigidbody", DroneDynamics: "drone"}
 _MSG_MAXREG = "exceeded max regularization term"  # traopt_controller.py:2984
@@ -307,9 +307,13 @@ class AL_iLQR_Tracking_SE3_MS(BaseController):
 class _FusedControllerSO3(_FusedController):
     def _get_solver(self, B):
         if self._solver is None or self._solver_batch < B:
-            if type(self.dynamics) is not SO3Dynamics or type(self.cost) is not SO3TrackingQuadraticGaussNewtonCost:
-                raise TypeError("the MI355X SO(3) path supports SO3Dynamics with SO3TrackingQuadraticGaussNewtonCost")
+            if type(self.dynamics) not in (SO3Dynamics, Pendulum3dDyanmics) or \
+                    type(self.cost) is not SO3TrackingQuadraticGaussNewtonCost:
+                raise TypeError("the MI355X SO(3) path supports SO3Dynamics / Pendulum3dDyanmics with "
+                                "SO3TrackingQuadraticGaussNewtonCost")
             prob = self.cost._embedded_problem(self.dynamics.J, self.dynamics.dt)
+            if type(self.dynamics) is Pendulum3dDyanmics:
+                prob.kind, prob.pend_mass, prob.pend_length = "pendulum3d", float(self.dynamics.m), float(self.dynamics.l)
             if prob.N != self.N:
                 raise ValueError("reference trajectory has %d knots, controller horizon N = %d" % (prob.N + 1, self.N))
             self._solver = BatchedTrackingILQR(prob, B)

@@ -235,3 +235,28 @@ class SO3Dynamics(BaseDynamics):
 
     def f_uu(self, x, u, i):
         raise NotImplementedError
+
+
+class Pendulum3dDyanmics(SO3Dynamics):
+    """A dynamics model for 3d pendulum actuated by the pivot point (traopt_dynamics.py:421-626; the class
+    name keeps the reference's spelling).  States are [SO3, SO3Tangent], the input is the pivot
+    acceleration in R^3; f_u depends on the state and the lower-left block of f_x on the input."""
+
+    def __init__(self, J, m, length, dt, integration_method="euler", state_size=(3, 3), action_size=3,
+                 hessians=False, debug=None, **kwargs):
+        super().__init__(J, dt, integration_method=integration_method, state_size=state_size,
+                         action_size=action_size, hessians=hessians, debug=debug, **kwargs)
+        self._m = m
+        self._l = length
+        self._g = 9.8  # traopt_dynamics.py:466
+
+    m = property(lambda self: self._m)
+    l = property(lambda self: self._l)  # noqa: E741  (the reference's property name)
+    g = property(lambda self: self._g)
+
+    def _probe(self):
+        if self._probe_solver is None:
+            J6 = np.eye(6)
+            J6[:3, :3] = self._J
+            self._probe_solver = _bridge.dynamics_probe("pendulum3d", J6, self._dt, self._m, self._l)
+        return self._probe_solver

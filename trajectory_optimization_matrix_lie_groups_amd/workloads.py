@@ -100,3 +100,22 @@ def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED):
     xi0 = np.ones(6) * 1e-3
     x0_q, x0_xi = perturbed_batch(q0, xi0, B, 0.1 * np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), 0.01, seed)
     return prob, x0_q, x0_xi, np.zeros((B, N, 4))
+
+
+def pendulum_swingup(B, xi0_scale=5.0, seed=SEED):
+    """Pendulum3dDyanmics swing-up tracking (main_pendulum3d_ddp_tracking_exact_ms.py:40-122,
+    benchmark_pendulum_swingup.py:50-72): path_3dpendulum_swingup (N=80, dt=0.025), J=diag(.5,.7,.9), m=1,
+    length=.5, Q=diag(10,10,10,1,1,1), P=10Q, R=1e-2 I3, q0 = from_euler('xy',[10,45] deg),
+    xi0 = (1,1,0)*xi0_scale (5 in the main script, 1 in the benchmark)."""
+    from .solver import embed_pendulum3d
+    R_ref, w_ref, dt = load_reference("pendulum_swingup_n80")
+    Q6 = np.diag([10.0, 10, 10, 1, 1, 1])
+    prob = embed_pendulum3d(np.diag([0.5, 0.7, 0.9]), 1.0, 0.5, dt, Q6, np.eye(3) * 1e-2, 10 * Q6, R_ref, w_ref)
+    x, y = np.deg2rad([10.0, 45.0])
+    Rx = np.array([[1.0, 0, 0], [0, np.cos(x), -np.sin(x)], [0, np.sin(x), np.cos(x)]])
+    Ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1.0, 0], [-np.sin(y), 0, np.cos(y)]])
+    q0 = np.eye(4)
+    q0[:3, :3] = Ry @ Rx  # extrinsic x then y
+    xi0 = np.array([1.0, 1.0, 0.0, 0, 0, 0]) * xi0_scale
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, np.array([0.3, 0.3, 0.3, 0, 0, 0]), np.array([0.1, 0.1, 0.1, 0, 0, 0]), seed)
+    return prob, x0_q, x0_xi, np.zeros((B, prob.N, 6))
