@@ -1,0 +1,96 @@
+"""BASELINE.json config 1: main_ddp.py cart-pole swing-up through the Euclidean iLQR / DDP plumbing
+(reference traoptlibrary/traopt_controller.py:42-520, traopt_dynamics.py:133-270, traopt_cost.py:113-290).
+
+Parity unpinned (no recorded run of main_ddp.py in the reference; its AutoDiff classes need jax).  The
+torch.func plumbing is checked against oracle/euclid_ilqr.py, which restates the solver in NumPy with
+complex-step derivatives and shares no code with it."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import euclid_ilqr as oe
+from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_controller import iLQR
+from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_cost import AutoDiffCost
+from trajectory_optimization_matrix_lie_groups_amd.traoptlibrary.traopt_dynamics import AutoDiffDynamics
+
+DT = 0.01
+X_GOAL = np.array([10.0, 0.0, math.pi, 0.0])
+
+
+def f(x, u):  # main_ddp.py:38-55 with torch ops
+    mc = mp = l = 1.0  # noqa: E741
+    g = 9.8
+    x1, x2, x3, x4 = x
+    u = u[0]
+    s, c = torch.sin(x3), torch.cos(x3)
+    dx2 = 1 / (mc + mp * s ** 2) * (u + mp * s * (l * x4 ** 2 + g * c))
+    dx4 = 1 / (l * mc + l * mp * s ** 2) * (-u * c - mp * l * x4 ** 2 * c * s - (mc + mp) * g * s)
+    return torch.stack([x2, dx2, x4, dx4])
+
+
+def fd_rk4(x, u, i):
+    s1 = f(x, u); s2 = f(x + DT / 2 * s1, u); s3 = f(x + DT / 2 * s2, u); s4 = f(x + DT * s3, u)
+    return x + DT / 6 * (s1 + 2 * s2 + 2 * s3 + s4)
+
+
+def l(x, u, i):  # noqa: E741  main_ddp.py:69-78
+    d = x - torch.as_tensor(X_GOAL, dtype=x.dtype)
+    Q = torch.diag(torch.tensor([100.0, 100.0, 10000.0, 100.0], dtype=x.dtype))
+    return 0.5 * u[0] * 200 * u[0] + 0.5 * d @ Q @ d
+
+
+def l_terminal(x, i):  # main_ddp.py:80-84
+    d = x - torch.as_tensor(X_GOAL, dtype=x.dtype)
+    Q = torch.diag(torch.tensor([100.0, 100.0, 10000.0, 100.0], dtype=x.dtype))
+    return 0.5 * d @ Q @ d
+
+
+def test_autodiff_plugins_match_complex_step():
+    dyn = AutoDiffDynamics(fd_rk4, 4, 1, hessians=True)
+    cost = AutoDiffCost(l, l_terminal, 4, 1)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        x = rng.normal(size=4); u = rng.normal(size=1) * 5
+        assert np.abs(dyn.f(x, u, 3) - oe.fd_rk4(x, u, DT)).max() < 1e-15
+        Fx, Fu = oe.jac(x, u, DT)
+        assert np.abs(dyn.f_x(x, u, 3) - Fx).max() < 1e-13 and np.abs(dyn.f_u(x, u, 3) - Fu).max() < 1e-13
+        Fxx, Fux, Fuu = oe.hess(x, u, DT)
+        assert np.abs(dyn.f_xx(x, u, 3) - Fxx).max() < 1e-7
+        assert np.abs(dyn.f_ux(x, u, 3) - Fux).max() < 1e-7
+        assert np.abs(dyn.f_uu(x, u, 3) - Fuu).max() < 1e-7
+        assert cost.l(x, u, 0) == pytest.approx(0.5 * 200 * u[0] ** 2 + 0.5 * (x - X_GOAL) @ oe.Q_X @ (x - X_GOAL), rel=1e-14)
+        assert np.abs(cost.l_x(x, u, 0) - oe.Q_X @ (x - X_GOAL)).max() < 1e-10
+        assert np.abs(cost.l_xx(x, u, 0) - oe.Q_X).max() < 1e-10
+        assert np.abs(cost.l_uu(x, u, 0) - 200).max() < 1e-12 and np.abs(cost.l_ux(x, u, 0)).max() == 0
+        assert cost.l(x, None, 5, terminal=True) == pytest.approx(0.5 * (x - X_GOAL) @ oe.Q_X @ (x - X_GOAL), rel=1e-14)
+    with pytest.raises(NotImplementedError):
+        AutoDiffDynamics(fd_rk4, 4, 1, hessians=False).f_xx(np.zeros(4), np.zeros(1), 0)
+    # knot-batched derivatives == per-knot ones
+    xs = rng.normal(size=(7, 4)); us = rng.normal(size=(7, 1))
+    assert np.abs(dyn.batch("f_x", xs, us) - np.stack([dyn.f_x(xs[i], us[i], i) for i in range(7)])).max() < 1e-14
+
+
+@pytest.mark.parametrize("hessians", [False, True])
+def test_cartpole_swingup_matches_numpy_restatement(hessians):
+    N, iters = 60, 12
+    x0 = np.array([9.0, 0.0, 0.0, 0.0])  # main_ddp.py:116
+    us0 = np.zeros((N, 1))
+    dyn = AutoDiffDynamics(fd_rk4, 4, 1, hessians=hessians)
+    cost = AutoDiffCost(l, l_terminal, 4, 1)
+    calls = []
+    ctl = iLQR(dyn, cost, N, hessians=hessians)
+    xs, us, J_hist, xs_hist, us_hist = ctl.fit(x0, us0, n_iterations=iters,
+                                               on_iteration=lambda *a: (calls.append(a[:9]), a[9].append(a[3])))
+    oxs, ous, h = oe.fit(x0, X_GOAL, us0, DT, n_iterations=iters, hessians=hessians)
+    assert len(calls) == len(h["J"]) and len(calls[0]) == 9  # 12 positional callback arguments (:209-211)
+    tol = 1e-5 if hessians else 1e-9  # the oracle's DDP tensors are finite differences
+    assert np.allclose([c[3] for c in calls], h["J"], rtol=tol)
+    assert [bool(c[4]) for c in calls] == h["accepted"]
+    assert np.allclose([c[7] for c in calls], h["alpha"]) and np.allclose([c[8] for c in calls], h["mu"])
+    assert np.allclose([c[6] for c in calls], h["grad"], rtol=max(tol, 1e-8))
+    assert np.abs(us - ous).max() < max(tol, 1e-8) * max(1.0, np.abs(ous).max())
+    assert J_hist == [c[3] for c in calls] and J_hist[-1] < J_hist[0]
+    assert xs.shape == (N + 1, 4) and us.shape == (N, 1)
+

@@ -407,3 +407,194 @@ class iLQR_Tracking_SO3_MS(_FusedControllerSO3):
     def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-6, tol_d_norm=1e-6, on_iteration=None):
         out = self._fit_so3(x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms=True)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Euclidean-space controller (traopt_controller.py:42-520): config 1 of BASELINE.json, host plumbing
+# ---------------------------------------------------------------------------------------------------
+class PDViolationError(Exception):
+    """Custom exception class for handling positive definite violation errors (traopt_controller.py:35-37)."""
+
+
+class iLQR(BaseController):
+    """Finite Horizon Iterative Linear Quadratic Regulator on a Euclidean state (traopt_controller.py:42-520),
+    with the true-DDP tensor terms when hessians=True (:487-490).
+
+    Generic plugin path: any BaseDynamics / BaseCost works through the per-knot methods; AutoDiffDynamics /
+    AutoDiffCost additionally expose knot-batched derivatives, which _forward_rollout uses to evaluate the
+    N Jacobians of a rollout in one torch.func.vmap call instead of N Python calls.  The solver arithmetic
+    (NumPy, fp64) follows the reference line by line, including its line-search and regularisation rules."""
+
+    def __init__(self, dynamics, cost, N, max_reg=1e10, hessians=False):
+        self.dynamics = dynamics
+        self.cost = cost
+        self.N = N
+        self._use_hessians = hessians and dynamics.has_hessians
+        if hessians and not dynamics.has_hessians:
+            warnings.warn("hessians requested but are unavailable in dynamics")
+        self._mu = 1.0
+        self._mu_min = 1e-6
+        self._mu_max = max_reg
+        self._delta_0 = 2.0
+        self._delta = self._delta_0
+        self._action_size = dynamics.action_size
+        self._state_size = dynamics.state_size
+        self._k = np.zeros((N, self._action_size))
+        self._K = np.zeros((N, self._action_size, self._state_size))
+
+    def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-3, on_iteration=None):
+        self._mu = 1.0
+        self._delta = self._delta_0
+        alphas = 1.1 ** (-np.arange(10) ** 2)
+        us = np.array(us_init, dtype=float)
+        k, K = self._k, self._K
+        J_hist, xs_hist, us_hist = [], [], []
+        changed = True
+        converged = False
+        alpha = alphas[0]
+        grad_wrt_input_norm = np.inf
+        for iteration in range(n_iterations):
+            accepted = False
+            if changed:
+                (xs, F_x, F_u, L, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu) = self._forward_rollout(x0, us)
+                J_opt = L.sum()
+                changed = False
+            try:
+                k, K = self._backward_pass(F_x, F_u, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu)
+                _, grad_wrt_input_norm = self._gradient_wrt_control(F_x, F_u, L_x, L_u)  # alpha independent (:166)
+                for alpha in alphas:
+                    xs_new, us_new = self._control(xs, us, k, K, alpha)
+                    J_new = self._trajectory_cost(xs_new, us_new)
+                    if grad_wrt_input_norm < tol_grad_norm:
+                        converged = True
+                        accepted = True
+                        break
+                    if J_new < J_opt:
+                        if np.abs((J_opt - J_new) / J_opt) < tol_J:
+                            converged = True
+                        J_opt = J_new
+                        xs = xs_new
+                        us = us_new
+                        changed = True
+                        self._delta = min(1.0, self._delta) / self._delta_0
+                        self._mu *= self._delta
+                        if self._mu <= self._mu_min:
+                            self._mu = 0.0
+                        accepted = True
+                        break
+            except np.linalg.LinAlgError as e:
+                warnings.warn(str(e))
+            if not accepted:
+                self._delta = max(1.0, self._delta) * self._delta_0
+                self._mu = max(self._mu_min, self._mu * self._delta)
+                if self._mu_max and self._mu >= self._mu_max:
+                    warnings.warn("exceeded max regularization term")
+                    break
+            if on_iteration:
+                on_iteration(iteration, xs, us, J_opt, accepted, converged, grad_wrt_input_norm, alpha, self._mu,
+                             J_hist, xs_hist, us_hist)
+            if converged:
+                break
+        self._k = k
+        self._K = K
+        self._nominal_xs = xs
+        self._nominal_us = us
+        return xs, us, J_hist, xs_hist, us_hist
+
+    def _control(self, xs, us, k, K, alpha=1.0):
+        xs_new = np.zeros_like(xs)
+        us_new = np.zeros_like(us)
+        xs_new[0] = xs[0].copy()
+        for i in range(self.N):
+            us_new[i] = us[i] + alpha * k[i] + K[i].dot(xs_new[i] - xs[i])
+            xs_new[i + 1] = self.dynamics.f(xs_new[i], us_new[i], i)
+        return xs_new, us_new
+
+    def _trajectory_cost(self, xs, us):
+        if hasattr(self.cost, "batch"):
+            J = float(np.sum(self.cost.batch("l", xs[:-1], us)))
+        else:
+            J = sum(self.cost.l(x, u, i) for i, (x, u) in enumerate(zip(xs[:-1], us)))
+        return J + self.cost.l(xs[-1], None, self.N, terminal=True)
+
+    def _forward_rollout(self, x0, us):
+        n, m, N = self.dynamics.state_size, self.dynamics.action_size, us.shape[0]
+        xs = np.empty((N + 1, n))
+        xs[0] = np.asarray(x0, dtype=float)
+        for i in range(N):
+            xs[i + 1] = self.dynamics.f(xs[i], us[i], i)
+        dyn_b, cost_b = hasattr(self.dynamics, "batch"), hasattr(self.cost, "batch")
+
+        def dyn(which, shape):
+            if dyn_b:
+                return self.dynamics.batch(which, xs[:-1], us).reshape((N,) + shape)
+            return np.stack([np.asarray(getattr(self.dynamics, which)(xs[i], us[i], i)).reshape(shape) for i in range(N)])
+
+        def cst(which, shape):
+            if cost_b:
+                return self.cost.batch(which, xs[:-1], us).reshape((N,) + shape)
+            return np.stack([np.asarray(getattr(self.cost, which)(xs[i], us[i], i, terminal=False)).reshape(shape)
+                             for i in range(N)])
+
+        F_x, F_u = dyn("f_x", (n, n)), dyn("f_u", (n, m))
+        F_xx = F_ux = F_uu = None
+        if self._use_hessians:
+            F_xx, F_ux, F_uu = dyn("f_xx", (n, n, n)), dyn("f_ux", (n, m, n)), dyn("f_uu", (n, m, m))
+        L = np.empty(N + 1)
+        L_x = np.empty((N + 1, n))
+        L_xx = np.empty((N + 1, n, n))
+        L[:N] = cst("l", ())
+        L_x[:N] = cst("l_x", (n,))
+        L_u = cst("l_u", (m,))
+        L_xx[:N] = cst("l_xx", (n, n))
+        L_ux = cst("l_ux", (m, n))
+        L_uu = cst("l_uu", (m, m))
+        x = xs[-1]
+        L[-1] = self.cost.l(x, None, N, terminal=True)
+        L_x[-1] = self.cost.l_x(x, None, N, terminal=True)
+        L_xx[-1] = self.cost.l_xx(x, None, N, terminal=True)
+        return xs, F_x, F_u, L, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu
+
+    def _backward_pass(self, F_x, F_u, L_x, L_u, L_xx, L_ux, L_uu, F_xx=None, F_ux=None, F_uu=None):
+        V_x = L_x[-1]
+        V_xx = L_xx[-1]
+        k = np.empty_like(self._k)
+        K = np.empty_like(self._K)
+        for i in range(self.N - 1, -1, -1):
+            if self._use_hessians:
+                Q_x, Q_u, Q_xx, Q_ux, Q_uu = self._Q(F_x[i], F_u[i], L_x[i], L_u[i], L_xx[i], L_ux[i], L_uu[i], V_x,
+                                                     V_xx, F_xx[i], F_ux[i], F_uu[i])
+            else:
+                Q_x, Q_u, Q_xx, Q_ux, Q_uu = self._Q(F_x[i], F_u[i], L_x[i], L_u[i], L_xx[i], L_ux[i], L_uu[i], V_x,
+                                                     V_xx)
+            k[i] = -np.linalg.solve(Q_uu, Q_u)   # the reference tests is_pos_def here and carries on (:398-399)
+            K[i] = -np.linalg.solve(Q_uu, Q_ux)
+            V_x = Q_x + K[i].T.dot(Q_uu).dot(k[i])
+            V_x += K[i].T.dot(Q_u) + Q_ux.T.dot(k[i])
+            V_xx = Q_xx + K[i].T.dot(Q_uu).dot(K[i])
+            V_xx += K[i].T.dot(Q_ux) + Q_ux.T.dot(K[i])
+            V_xx = 0.5 * (V_xx + V_xx.T)
+        return np.array(k), np.array(K)
+
+    def _Q(self, f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx, f_xx=None, f_ux=None, f_uu=None):
+        Q_x = l_x + f_x.T.dot(V_x)
+        Q_u = l_u + f_u.T.dot(V_x)
+        Q_xx = l_xx + f_x.T.dot(V_xx).dot(f_x)
+        reg = self._mu * np.eye(self.dynamics.state_size)
+        Q_ux = l_ux + f_u.T.dot(V_xx + reg).dot(f_x)
+        Q_uu = l_uu + f_u.T.dot(V_xx + reg).dot(f_u)
+        if self._use_hessians:
+            Q_xx = Q_xx + np.tensordot(V_x, f_xx, axes=1)
+            Q_ux = Q_ux + np.tensordot(V_x, f_ux, axes=1)
+            Q_uu = Q_uu + np.tensordot(V_x, f_uu, axes=1)
+        return Q_x, Q_u, Q_xx, Q_ux, Q_uu
+
+    def _gradient_wrt_control(self, F_x, F_u, L_x, L_u):
+        g = np.zeros((self.N, self._action_size))
+        p = L_x[self.N]
+        g_norm_sum = 0
+        for t in range(self.N - 1, -1, -1):
+            g[t] = L_u[t] + np.matmul(F_u[t].T, p)
+            p = L_x[t] + np.matmul(F_x[t].T, p)
+            g_norm_sum = g_norm_sum + np.linalg.norm(g[t])
+        return g, g_norm_sum / self.N

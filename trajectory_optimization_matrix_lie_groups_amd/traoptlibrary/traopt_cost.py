@@ -240,3 +240,48 @@ class SO3TrackingQuadraticGaussNewtonCost(BaseCost):
 
     def l_uu(self, x, u, i, terminal=False):
         return 2 * self._R
+
+
+class AutoDiffCost(BaseCost):
+    """Auto-differentiated Instantaneous Cost (traopt_cost.py:113-290) on torch.func: l(x, u, i) and
+    l_terminal(x, i) take torch tensors and return a scalar tensor."""
+
+    def __init__(self, l, l_terminal, state_size, action_size, device=None, **kwargs):  # noqa: E741
+        from ._autodiff import Derivs
+        self._state_size = state_size
+        self._action_size = action_size
+        self._d = Derivs(l, second=True, device=device)
+        self._t = Derivs(lambda x, u, i: l_terminal(x, i), second=True, device=device)
+
+    state_size = property(lambda self: self._state_size)
+    action_size = property(lambda self: self._action_size)
+
+    def _zu(self):
+        return np.zeros(self._action_size)
+
+    def l(self, x, u, i, terminal=False):  # noqa: E741
+        return float(self._t.one("fn", x, self._zu(), i)) if terminal else float(self._d.one("fn", x, u, i))
+
+    def l_x(self, x, u, i, terminal=False):
+        return self._t.one("fx", x, self._zu(), i) if terminal else self._d.one("fx", x, u, i)
+
+    def l_u(self, x, u, i, terminal=False):
+        return np.zeros(self._action_size) if terminal else self._d.one("fu", x, u, i)  # traopt_cost.py:230-232
+
+    def l_xx(self, x, u, i, terminal=False):
+        return self._t.one("fxx", x, self._zu(), i) if terminal else self._d.one("fxx", x, u, i)
+
+    def l_ux(self, x, u, i, terminal=False):
+        if terminal:
+            return np.zeros((self._action_size, self._state_size))
+        return self._d.one("fux", x, u, i)
+
+    def l_uu(self, x, u, i, terminal=False):
+        if terminal:
+            return np.zeros((self._action_size, self._action_size))
+        return self._d.one("fuu", x, u, i)
+
+    def batch(self, which, xs, us):
+        """l / l_x / l_u / l_xx / l_ux / l_uu for all stage knots in one vmapped call."""
+        return self._d.batch({"l": "fn", "l_x": "fx", "l_u": "fu", "l_xx": "fxx", "l_ux": "fux", "l_uu": "fuu"}[which],
+                             xs, us)

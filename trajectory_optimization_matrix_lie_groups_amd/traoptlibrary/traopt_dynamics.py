@@ -260,3 +260,48 @@ class Pendulum3dDyanmics(SO3Dynamics):
             J6[:3, :3] = self._J
             self._probe_solver = _bridge.dynamics_probe("pendulum3d", J6, self._dt, self._m, self._l)
         return self._probe_solver
+
+
+class AutoDiffDynamics(BaseDynamics):
+    """Auto-differentiated Dynamics Model (traopt_dynamics.py:133-270), on torch.func where the reference
+    uses jax: f(x, u, i) takes and returns torch tensors.  Config 1 of BASELINE.json (main_ddp.py) is
+    plumbing around this class and the Euclidean iLQR."""
+
+    def __init__(self, f, state_size, action_size, hessians=False, device=None, **kwargs):
+        from ._autodiff import Derivs
+        self._state_size = state_size
+        self._action_size = action_size
+        self._has_hessians = hessians
+        self._d = Derivs(f, second=hessians, device=device)
+
+    state_size = property(lambda self: self._state_size)
+    action_size = property(lambda self: self._action_size)
+    has_hessians = property(lambda self: self._has_hessians)
+
+    def f(self, x, u, i):
+        return self._d.one("fn", x, u, i)
+
+    def f_x(self, x, u, i):
+        return self._d.one("fx", x, u, i)
+
+    def f_u(self, x, u, i):
+        return self._d.one("fu", x, u, i)
+
+    def f_xx(self, x, u, i):
+        if not self._has_hessians:
+            raise NotImplementedError
+        return self._d.one("fxx", x, u, i)
+
+    def f_ux(self, x, u, i):
+        if not self._has_hessians:
+            raise NotImplementedError
+        return self._d.one("fux", x, u, i)
+
+    def f_uu(self, x, u, i):
+        if not self._has_hessians:
+            raise NotImplementedError
+        return self._d.one("fuu", x, u, i)
+
+    def batch(self, which, xs, us):
+        """f_x / f_u / f_xx / f_ux / f_uu for all knots of a rollout in one vmapped call."""
+        return self._d.batch({"f_x": "fx", "f_u": "fu", "f_xx": "fxx", "f_ux": "fux", "f_uu": "fuu"}[which], xs, us)
