@@ -149,29 +149,12 @@ def manifse32se3(x):
     return np.concatenate((x[3:], x[:3]))
 
 
-class SE3:
-    """The slice of ``manifpy.SE3`` the reference's scripts use to build initial states
-    (benchmark_SE3_tracking.py:67-70): SE3(position=, quaternion=xyzw).transform()."""
+from ..manifpy_compat import SE3, SE3Tangent, SO3, SO3Tangent  # noqa: E402,F401  (the reference imports these from manifpy)
 
-    def __init__(self, position, quaternion):
-        self._t = np.asarray(position, dtype=float).reshape(3)
-        q = np.asarray(quaternion, dtype=float).reshape(4)
-        self._q = q / np.linalg.norm(q)
 
-    def transform(self):
-        T = np.eye(4)
-        T[:3, :3] = Rotation.from_quat(self._q).as_matrix()
-        T[:3, 3] = self._t
-        return T
-
-    def rotation(self):
-        return Rotation.from_quat(self._q).as_matrix()
-
-    def translation(self):
-        return self._t.copy()
-
-    def coeffs(self):
-        return np.concatenate((self._t, self._q))
+def se32manifse3(x):
+    """twist [w, v] -> manif SE3Tangent ([v, w]) (traopt_utilis.py:356-367)"""
+    return SE3Tangent(se32manifse3_coeffs(x))
 
 
 def SE32manifSE3(x):
@@ -187,56 +170,6 @@ def manifSE32SE3(x):
 
 def parallel_SE32manifSE3(q_ref):
     return [SE32manifSE3(q) for q in q_ref]
-
-
-class SO3:
-    """The slice of ``manifpy.SO3`` the SO(3) scripts touch (main_SO3ddp_tracking_exact.py:87, :150-163):
-    SO3(quaternion xyzw), .rotation(), .coeffs(), .quat().  Group arithmetic (lminus, *, inverse ...) is
-    not reimplemented on the host: the solvers do it on the device."""
-    DoF = 3
-
-    def __init__(self, quaternion):
-        q = np.asarray(quaternion, dtype=float).reshape(4)
-        self._q = q / np.linalg.norm(q)
-
-    @classmethod
-    def from_matrix(cls, R):
-        return cls(Rotation.from_matrix(np.asarray(R, float)).as_quat())
-
-    def rotation(self):
-        return Rotation.from_quat(self._q).as_matrix()
-
-    def coeffs(self):
-        return self._q.copy()
-
-    def quat(self):
-        return self._q.copy()
-
-    def transform(self):
-        T = np.eye(4)
-        T[:3, :3] = self.rotation()
-        return T
-
-
-class SO3Tangent:
-    """manifpy.SO3Tangent holder: coefficient vector (3,) and the scalar arithmetic scripts use."""
-
-    def __init__(self, w):
-        self._w = np.asarray(w, dtype=float).reshape(3).copy()
-
-    def coeffs(self):
-        return self._w.copy()
-
-    def __mul__(self, s):
-        return SO3Tangent(self._w * float(s))
-
-    __rmul__ = __mul__
-
-    def __add__(self, o):
-        return SO3Tangent(self._w + o._w)
-
-    def __sub__(self, o):
-        return SO3Tangent(self._w - o._w)
 
 
 def SO32manifSO3(x):
