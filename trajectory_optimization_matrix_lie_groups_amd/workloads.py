@@ -119,3 +119,41 @@ def pendulum_swingup(B, xi0_scale=5.0, seed=SEED):
     xi0 = np.array([1.0, 1.0, 0.0, 0, 0, 0]) * xi0_scale
     x0_q, x0_xi = perturbed_batch(q0, xi0, B, np.array([0.3, 0.3, 0.3, 0, 0, 0]), np.array([0.1, 0.1, 0.1, 0, 0, 0]), seed)
     return prob, x0_q, x0_xi, np.zeros((B, prob.N, 6))
+
+
+def so3_tracking(B=1, N=100, seed=SEED):
+    """Config 2: SO3 exact tracking (main_SO3ddp_tracking_exact.py:75-125): first N+1 knots of
+    path_3dpendulum_8shape (dt=.04), J=diag(.5,.7,.9), Q=diag(10,10,10,1,1,1), P=10Q, R=1e-5 I3,
+    x0 = (q_ref[0], xi_ref[0]); members b > 0 are perturbed in rotation / angular velocity."""
+    from .solver import embed_so3
+    R_ref, w_ref, dt = load_reference("so3_8shape_n249")
+    R_ref, w_ref = R_ref[: N + 1], w_ref[: N + 1]
+    Q6 = np.diag([10.0, 10, 10, 1, 1, 1])
+    prob = embed_so3(np.diag([0.5, 0.7, 0.9]), dt, Q6, np.eye(3) * 1e-5, 10 * Q6, R_ref, w_ref)
+    q0 = np.eye(4)
+    q0[:3, :3] = R_ref[0]
+    xi0 = np.r_[w_ref[0], 0, 0, 0]
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, np.array([0.3, 0.3, 0.3, 0, 0, 0]), np.array([0.1, 0.1, 0.1, 0, 0, 0]), seed)
+    return prob, x0_q, x0_xi, np.zeros((B, N, 6))
+
+
+def al_tracking(B, N=200, seed=SEED):
+    """Config 4: SE3 AL-DDP multiple shooting with input box constraints
+    (main_SE3ddp_tracking_exact_al_ms.py:47-152): constant-twist reference xi_ref=[0,0,1,2,0,.2], dt=.01,
+    Q=diag(10,10,10,1,...,1), P=10Q, R=0, InputConstraint(-10,10), nominal x0=[I,(-1,-1,-.2)],
+    xi0=[0,0,.1,2,0,.2].  Returns (prob, x0_q, x0_xi, us_init, lb, ub)."""
+    dt = 0.01
+    xi_c = np.array([0.0, 0.0, 1.0, 2.0, 0.0, 0.2])
+    step = _se3_exp(xi_c * dt)
+    q_ref = np.empty((N + 1, 4, 4))
+    q_ref[0] = np.eye(4)
+    for i in range(N):
+        q_ref[i + 1] = q_ref[i] @ step
+    xi_ref = np.repeat(xi_c[None], N + 1, 0)
+    Q = np.diag([10.0, 10, 10, 1, 1, 1, 1, 1, 1, 1, 1, 1])
+    prob = TrackingProblem("se3", inertia(), dt, Q, np.zeros((6, 6)), 10 * Q, q_ref, xi_ref)
+    q0 = np.eye(4)
+    q0[:3, 3] = [-1.0, -1.0, -0.2]
+    xi0 = np.array([0.0, 0.0, 0.1, 2.0, 0.0, 0.2])
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, 0.3 * np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), 0.05, seed)
+    return prob, x0_q, x0_xi, np.zeros((B, N, 6)), -10.0 * np.ones(6), 10.0 * np.ones(6)
