@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=40)
     args = ap.parse_args()
 
     import torch

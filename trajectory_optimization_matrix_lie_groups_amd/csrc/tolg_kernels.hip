@@ -1847,7 +1847,7 @@ struct tolg_handle_s {
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
   hipStream_t st2;        // library-owned streams for the rollout / re-linearisation overlap:
   hipStream_t st_roll;    // st2 runs K1, st_roll (null: the caller's stream) the segmented K3
-  hipEvent_t seg_ev[8];
+  hipEvent_t seg_ev[34];  // up to 32 segments + 2
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -2207,7 +2207,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
     if (!opt->line_search && h->st2 && P.N >= 8) {
       // accept-always rollout: issue it in NSEG segments and re-linearise every finished segment on
       // the library's second stream meanwhile (disjoint CU masks, see tolg_create)
-      const int NSEG = 4;
+      static const int nseg_env = getenv("TOLG_OVERLAP_SEGS") ? atoi(getenv("TOLG_OVERLAP_SEGS")) : 4;
+      const int NSEG = nseg_env < 2 ? 2 : (nseg_env > 32 ? 32 : nseg_env);
       hipStream_t sr = h->st_roll ? h->st_roll : st;
       if (h->st_roll) {
         if (hipEventRecord(h->seg_ev[NSEG + 1], st) != hipSuccess) return TOLG_E_LAUNCH;
