@@ -122,17 +122,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # final gather of costs / controls over RCCL (outside the timed solve, reported separately)
-    gather_ms = None
+    gather_ms, gather_err = None, None
     if world > 1:
-        Jf = res.J_hist[:, W + K - 1].contiguous()
-        outJ = [torch.empty_like(Jf) for _ in range(world)]
-        outU = [torch.empty_like(res.us) for _ in range(world)]
-        torch.cuda.synchronize(dev)
-        g0 = time.perf_counter()
-        dist.all_gather(outJ, Jf)
-        dist.all_gather(outU, res.us)
-        torch.cuda.synchronize(dev)
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        try:
+            Jf = res.J_hist[:, W + K - 1].contiguous()
+            outJ = [torch.empty_like(Jf) for _ in range(world)]
+            outU = [torch.empty_like(res.us) for _ in range(world)]
+            torch.cuda.synchronize(dev)
+            g0 = time.perf_counter()
+            dist.all_gather(outJ, Jf)
+            dist.all_gather(outU, res.us)
+            torch.cuda.synchronize(dev)
+            gather_ms = (time.perf_counter() - g0) * 1e3
+        except Exception as e:  # the timed figure above stands on its own; say what happened to the gather
+            gather_err = "%s: %s" % (type(e).__name__, e)
     finite = bool(torch.isfinite(res.J_hist[:, : W + K]).all().item())
 
     if rank == 0:
@@ -153,7 +156,7 @@ def main():
                        "trajectory_iterations_per_s": value * B, "all_finite": finite,
                        "kernel_ms_per_step": {"backward": ms_b / max(n_b, 1), "rollout": ms_r / max(n_b, 1),
                                               "linearize": ms_l / max(n_b, 1)},
-                       "final_gather_ms": gather_ms},
+                       "final_gather_ms": gather_ms, **({"final_gather_error": gather_err} if gather_err else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -874,8 +874,10 @@ TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
   }
 }
 
-// VARB: F_u differs from knot to knot (Pendulum3dDyanmics): its 3x3 block is read from REC_BU
-template <int M, bool VARB = false>
+// VARB: F_u differs from knot to knot (Pendulum3dDyanmics): its 3x3 block is read from REC_BU.
+// GRAV: the model has a gravity block A21 in F_x (Drone / RigidBody / Pendulum); SE3 / SO3 instantiate
+// without it and save its 18 per-lane coefficients (36 VGPRs in a kernel that already spills to AGPRs).
+template <int M, bool VARB = false, bool GRAV = true>
 __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
@@ -888,18 +890,26 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // lane-dependent constants
   const double m12 = (j < 12) ? 1.0 : 0.0;                  // matrix columns
   const double mvec = (j == 12 || j == 13) ? 1.0 : 0.0;     // vector columns (V_x, SS adjoint)
-  const bool grav = C.grav != 0.0;
-  double W2col[6], Rcol[M], Bloc[6], Brow[M];
+  constexpr bool grav = GRAV;
+  // Per-lane constant columns (2 W2, 2 R, and the two views of F_u).  They live in LDS, not in 48 VGPRs:
+  // the kernel is far over the 256 architectural registers and every value parked in an AGPR costs a
+  // v_accvgpr copy per use, while LDS is otherwise idle here.  Row stride 25 doubles: conflict-free.
+  __shared__ double KC[16][25];
+  enum { KC_W2 = 0, KC_R = 6, KC_BLOC = 12, KC_BROW = 18 };
+  if (g == 0) {
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-    W2col[r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
-    Bloc[r] = (j < M) ? fu_entry<M>(C, r, j) : 0.0;          // B[6+r][j]
-  }
+    for (int r = 0; r < 6; r++) {
+      KC[j][KC_W2 + r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
+      KC[j][KC_BLOC + r] = (j < M) ? fu_entry<M>(C, r, j) : 0.0;          // B[6+r][j]
+    }
 #pragma unroll
-  for (int u = 0; u < M; u++) {
-    Rcol[u] = (j < M) ? 2.0 * C.R[u * M + j] : 0.0;
-    Brow[u] = (j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u) : 0.0;  // B[j][u]
+    for (int u = 0; u < 6; u++) {
+      KC[j][KC_R + u] = (u < M && j < M) ? 2.0 * C.R[(u < M ? u : 0) * M + j] : 0.0;
+      KC[j][KC_BROW + u] = (u < M && j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
+    }
   }
+  __builtin_amdgcn_wave_barrier();
+  const double* KCj = KC[j];
   // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
   int fT = REC_D, fM = REC_D + 3;
   double mT = 0.0, mM = 0.0;
@@ -925,11 +935,13 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   for (int r = 0; r < 6; r++) vL[r] = vr + (unsigned)fL[r] * REC_SR;
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   const double mB = ((j >= 6 && j < 12) || j == 12) ? 1.0 : 0.0;
-  double Cg[3][6];
+  double Cg[GRAV ? 3 : 1][6];
+  if constexpr (GRAV) {
 #pragma unroll
-  for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int r = 0; r < 6; r++) Cg[a][r] = (j < 3 && grav) ? C.Llin[a][6 * r + (j < 3 ? j : 0)] : 0.0;
+      for (int r = 0; r < 6; r++) Cg[a][r] = (j < 3) ? C.Llin[a][6 * r + (j < 3 ? j : 0)] : 0.0;
+  }
   double mu = P.mu[b], delta = P.delta[b];
   int warned = 0;
 
@@ -950,7 +962,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
   // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
   // data right behind the request and undo the prefetch.
-  struct BwdIn { double t[3], m[3], bt[6], g[3], lt[6], lb[6], lu[M], luu, bu[VARB ? 9 : 1]; };
+  struct BwdIn { double t[3], m[3], bt[6], g[GRAV ? 3 : 1], lt[6], lb[6], lu[M], luu, bu[VARB ? 9 : 1]; };
   auto load_knot = [&](int i, BwdIn& in) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
 #pragma unroll
@@ -960,7 +972,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) in.bt[r] = bld(rR, vBt, r * REC_SR);
-    if (grav) {
+    if constexpr (GRAV) {
 #pragma unroll
       for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), (REC_RTE + a) * REC_SR);
     }
@@ -986,28 +998,14 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 3; r++) { A[r] = mT * in.t[r]; A[3 + r] = mM * in.m[r]; }
 #pragma unroll
     for (int r = 0; r < 6; r++) A[6 + r] = mB * in.bt[r];
-    if (grav) {
+    if constexpr (GRAV) {
 #pragma unroll
       for (int r = 0; r < 6; r++) A[6 + r] += in.g[0] * Cg[0][r] + in.g[1] * Cg[1][r] + in.g[2] * Cg[2][r];
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r] + W2col[r]; }
+    for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r]; }  // + 2 W2: added to Qh below
 #pragma unroll
     for (int a = 0; a < M; a++) lu[a] = mvec * in.lu[a];  // l_u = 2 R u rides in the vector columns
-    // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
-    double BtS[VARB ? 9 : 1], BlocS[VARB ? 6 : 1], BrowS[VARB ? M : 1];
-    if constexpr (VARB) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) BtS[k] = in.bu[k];
-#pragma unroll
-      for (int r = 0; r < 6; r++) BlocS[r] = Bloc[r];
-#pragma unroll
-      for (int u = 0; u < M; u++) BrowS[u] = Brow[u];
-#pragma unroll
-      for (int r = 0; r < 3; r++) BlocS[r] = (j == 0) ? BtS[3 * r] : (j == 1) ? BtS[3 * r + 1] : (j == 2) ? BtS[3 * r + 2] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 3; u++) BrowS[u] = (j == 6) ? BtS[u] : (j == 7) ? BtS[3 + u] : (j == 8) ? BtS[6 + u] : 0.0;
-    }
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
 #pragma unroll
@@ -1024,7 +1022,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     // F_x = [Ri 0 Jr 0; TRi Ri Qr Jr; A21 0 A22 A22]: skip the structurally zero 3-row blocks
     rank1_bi_02(Qh, A[0], Z[0]); rank1_bi_02(Qh, A[1], Z[1]); rank1_bi_02(Qh, A[2], Z[2]);
     rank1_bi(Qh, A[3], Z[3]); rank1_bi(Qh, A[4], Z[4]); rank1_bi(Qh, A[5], Z[5]);
-    if (grav) {
+    if constexpr (GRAV) {
       rank1_bi_023(Qh, A[6], Z[6]); rank1_bi_023(Qh, A[7], Z[7]); rank1_bi_023(Qh, A[8], Z[8]);
       rank1_bi_023(Qh, A[9], Z[9]); rank1_bi_023(Qh, A[10], Z[10]); rank1_bi_023(Qh, A[11], Z[11]);
     } else {
@@ -1037,81 +1035,114 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     // regularisation / Cholesky / gain / V-update half of the step runs.  One buffer instead of a
     // ping-pong pair keeps the loads in VGPRs (with two, the allocator parked them in AGPRs and had to
     // wait for them right away to copy them back).
+    // Constants of the second half, requested BEFORE the prefetch so that their LDS / scalar-cache
+    // latency passes while the 31 buffer loads issue (read where they are used, each cost an exposed
+    // lgkmcnt(0) wait: ~10 per knot).
+    double kW2[6], kR[M], kBloc[6], kBrow[M], cBt[9], cBb[9];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { kW2[r] = KCj[KC_W2 + r]; kBloc[r] = KCj[KC_BLOC + r]; }
+#pragma unroll
+    for (int u = 0; u < M; u++) { kR[u] = KCj[KC_R + u]; kBrow[u] = KCj[KC_BROW + u]; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { cBt[k] = C.Bt[k]; cBb[k] = C.Bb[k]; }
+    // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
+    double BtS[VARB ? 9 : 1], BlocS[VARB ? 6 : 1], BrowS[VARB ? M : 1];
+    if constexpr (VARB) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) BtS[k] = in.bu[k];
+#pragma unroll
+      for (int r = 0; r < 6; r++) BlocS[r] = kBloc[r];
+#pragma unroll
+      for (int u = 0; u < M; u++) BrowS[u] = kBrow[u];
+#pragma unroll
+      for (int r = 0; r < 3; r++) BlocS[r] = (j == 0) ? BtS[3 * r] : (j == 1) ? BtS[3 * r + 1] : (j == 2) ? BtS[3 * r + 2] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 3; u++) BrowS[u] = (j == 6) ? BtS[u] : (j == 7) ? BtS[3 + u] : (j == 8) ? BtS[6 + u] : 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (i > 0) load_knot(i - 1, in);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 6; r++) Qh[6 + r] += kW2[r];
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
-    double Quh[M], Kh[M];
-    bool done = !act;  // inactive trajectories skip the loop body but keep EXEC rows uniform
+    double Quh[M], Kh[M], Ls[M][M], dinv[M], Qrep[M][M];
     bool use_lu = false;
-    double Ls[M][M], dinv[M], Qrep[M][M];
+    // one regularisation attempt with the current mu: Q_ux | Q_u, Q_uu, Cholesky of its symmetric part
+    auto attempt = [&]() -> bool {
+      const double muA = m12 * mu;
+      // X' = (V + mu I) F_x, rows 6..11 (B has no other non-zero rows); vector columns: w
+      double Xp[6];
 #pragma unroll
-    for (int u = 0; u < M; u++) { Quh[u] = 0; Kh[u] = 0; dinv[u] = 1; }
-    if (!act) {
+      for (int k = 0; k < 6; k++) Xp[k] = Z[6 + k] + muA * A[6 + k];
+      // T = B^T (V + mu I), rows u, column per lane
+      double T[M];
 #pragma unroll
-      for (int u = 0; u < M; u++)
+      for (int u = 0; u < M; u++) {  // B2 is block diagonal: inputs 0..2 see rows 6..8, the rest rows 9..11
+        double s = lu[u], tt = muA * (VARB ? BrowS[VARB ? u : 0] : kBrow[u]);
+        const int k0 = (u < 3) ? 0 : 3;
 #pragma unroll
-        for (int k = 0; k < M; k++) { Ls[u][k] = (u == k); Qrep[u][k] = (u == k); }
-    }
-    for (;;) {
-      if (!done) {
-        const double muA = m12 * mu;
-        // X' = (V + mu I) F_x, rows 6..11 (B has no other non-zero rows); vector columns: w
-        double Xp[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) Xp[k] = Z[6 + k] + muA * A[6 + k];
-        // T = B^T (V + mu I), rows u, column per lane
-        double T[M];
-#pragma unroll
-        for (int u = 0; u < M; u++) {  // B2 is block diagonal: inputs 0..2 see rows 6..8, the rest rows 9..11
-          double s = lu[u], tt = muA * (VARB ? BrowS[VARB ? u : 0] : Brow[u]);
-          const int k0 = (u < 3) ? 0 : 3;
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const double bku = (u < 3) ? (VARB ? BtS[VARB ? 3 * k + u : 0] : C.Bt[3 * k + u]) : C.Bb[3 * k + (u - 3)];
-            s += bku * Xp[k0 + k];
-            tt += bku * V[6 + k0 + k];
-          }
-          Quh[u] = s;
-          T[u] = m12 * tt;
+        for (int k = 0; k < 3; k++) {
+          const double bku = (u < 3) ? (VARB ? BtS[VARB ? 3 * k + u : 0] : cBt[3 * k + u]) : cBb[3 * k + (u - 3)];
+          s += bku * Xp[k0 + k];
+          tt += bku * V[6 + k0 + k];
         }
-        // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
-        double Quu[M];
+        Quh[u] = s;
+        T[u] = m12 * tt;
+      }
+      // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
+      double Quu[M];
 #pragma unroll
-        for (int u = 0; u < M; u++) Quu[u] = Rcol[u] + ((j == u) ? luu_i : 0.0);
-        if constexpr (VARB) {
-          quu_acc<M, 6>(Quu, T, BlocS[0]); quu_acc<M, 7>(Quu, T, BlocS[1]); quu_acc<M, 8>(Quu, T, BlocS[2]);
-          quu_acc<M, 9>(Quu, T, BlocS[3 % (VARB ? 6 : 1)]); quu_acc<M, 10>(Quu, T, BlocS[4 % (VARB ? 6 : 1)]);
-          quu_acc<M, 11>(Quu, T, BlocS[5 % (VARB ? 6 : 1)]);
-        } else {
-          quu_acc<M, 6>(Quu, T, Bloc[0]); quu_acc<M, 7>(Quu, T, Bloc[1]); quu_acc<M, 8>(Quu, T, Bloc[2]);
-          quu_acc<M, 9>(Quu, T, Bloc[3]); quu_acc<M, 10>(Quu, T, Bloc[4]); quu_acc<M, 11>(Quu, T, Bloc[5]);
-        }
-        // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
-        // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
+      for (int u = 0; u < M; u++) Quu[u] = kR[u] + ((j == u) ? luu_i : 0.0);
+      if constexpr (VARB) {
+        quu_acc<M, 6>(Quu, T, BlocS[0]); quu_acc<M, 7>(Quu, T, BlocS[1]); quu_acc<M, 8>(Quu, T, BlocS[2]);
+        quu_acc<M, 9>(Quu, T, BlocS[3 % (VARB ? 6 : 1)]); quu_acc<M, 10>(Quu, T, BlocS[4 % (VARB ? 6 : 1)]);
+        quu_acc<M, 11>(Quu, T, BlocS[5 % (VARB ? 6 : 1)]);
+      } else {
+        quu_acc<M, 6>(Quu, T, kBloc[0]); quu_acc<M, 7>(Quu, T, kBloc[1]); quu_acc<M, 8>(Quu, T, kBloc[2]);
+        quu_acc<M, 9>(Quu, T, kBloc[3]); quu_acc<M, 10>(Quu, T, kBloc[4]); quu_acc<M, 11>(Quu, T, kBloc[5]);
+      }
+      // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
+      // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
 #pragma unroll
-        for (int u = 0; u < M; u++) {
-          Qrep[u][0] = bcast<0>(Quu[u]);
-          if (u >= 1) Qrep[u][1] = bcast<1>(Quu[u]);
-          if (u >= 2) Qrep[u][2] = bcast<2>(Quu[u]);
-          if (u >= 3) Qrep[u][3] = bcast<3>(Quu[u]);
-          if constexpr (M > 4) {
-            if (u >= 4) Qrep[u][4] = bcast<4>(Quu[u]);
-            if (u >= 5) Qrep[u][5] = bcast<5>(Quu[u]);
-          }
-        }
-        bool pd = chol_sym<M>(Ls, Qrep, dinv);
-        if (!pd) {
-          delta = fmax(1.0, delta) * 2.0;
-          mu = fmax(1e-6, mu * delta);
-          if (P.max_reg > 0 && mu >= P.max_reg) { warned = 1; use_lu = true; done = true; }
-        } else {
-          delta = fmin(1.0, delta) * 0.5;
-          mu *= delta;
-          if (mu <= 1e-6) mu = 0.0;
-          done = true;
+      for (int u = 0; u < M; u++) {
+        Qrep[u][0] = bcast<0>(Quu[u]);
+        if (u >= 1) Qrep[u][1] = bcast<1>(Quu[u]);
+        if (u >= 2) Qrep[u][2] = bcast<2>(Quu[u]);
+        if (u >= 3) Qrep[u][3] = bcast<3>(Quu[u]);
+        if constexpr (M > 4) {
+          if (u >= 4) Qrep[u][4] = bcast<4>(Quu[u]);
+          if (u >= 5) Qrep[u][5] = bcast<5>(Quu[u]);
         }
       }
-      if (__all(done)) break;
+      return chol_sym<M>(Ls, Qrep, dinv);
+    };
+    // regularisation schedule (traopt_controller.py:2975-2995); returns true when this knot is settled
+    auto schedule = [&](bool pd) -> bool {
+      if (!pd) {
+        delta = fmax(1.0, delta) * 2.0;
+        mu = fmax(1e-6, mu * delta);
+        if (P.max_reg > 0 && mu >= P.max_reg) { warned = 1; use_lu = true; return true; }
+        return false;
+      }
+      delta = fmin(1.0, delta) * 0.5;
+      mu *= delta;
+      if (mu <= 1e-6) mu = 0.0;
+      return true;
+    };
+    // The first attempt runs for every lane, straight-line (inactive trajectories compute on stale data
+    // and ignore the outcome): as the body of a retry loop it cost ~50 register initialisations per knot
+    // for the loop-carried factors.  The retry loop itself is entered only when some active trajectory
+    // of this wavefront failed the PD test.
+    bool done = true;
+    {
+      const bool pd = attempt();
+      if (act) done = schedule(pd);
+    }
+    if (!__all(done)) {
+      for (;;) {
+        if (!done) done = schedule(attempt());
+        if (__all(done)) break;
+      }
     }
     // gradient term: ||Q_u|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
     {
@@ -2154,9 +2185,11 @@ template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   Timed t(h, st, 0);
   if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
-    hipLaunchKernelGGL((k_backward<6, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+    hipLaunchKernelGGL((k_backward<6, true, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+  else if (M == 6 && h->hc.grav == 0.0)
+    hipLaunchKernelGGL((k_backward<6, false, false>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
   else
-    hipLaunchKernelGGL(k_backward<M>, dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+    hipLaunchKernelGGL((k_backward<M, false, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
   LAUNCH_CHECK();
   return 0;
 }
