@@ -236,6 +236,51 @@ TOLG_DEV State dyn_f(const CT& C, const State& S, const double (&u)[M]) {
   return F;
 }
 
+// The constants of the diagonal-inertia path, pinned in vector registers for the sequential rollout.
+// Read on demand they are scalar loads the allocator prefers to re-issue over keeping 28 SGPRs alive:
+// fourteen `s_load; s_waitcnt lgkmcnt(0)` pairs per knot, each an exposed scalar-cache round trip on a
+// wave that has nothing else to run.
+struct DynK { double dt, ib[3], jv[3], bt[3], jvi[3], mg; bool diag; };
+TOLG_DEV double pin_v(double x) { asm volatile("" : "+v"(x)); return x; }
+template <class CT>
+TOLG_DEV DynK dynk_load(const CT& C) {
+  DynK K;
+  K.diag = C.diagJ != 0;
+  K.dt = pin_v(C.dt);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    K.ib[a] = pin_v(C.Ib[4 * a]); K.jv[a] = pin_v(C.Jv[4 * a]);
+    K.bt[a] = pin_v(C.Bt[4 * a]); K.jvi[a] = pin_v(C.Jvinv[4 * a]);
+  }
+  K.mg = pin_v(C.mass * C.grav);
+  return K;
+}
+// dyn_f with the pinned constants: the same expressions in the same order as the diagJ branch above
+template <int M, class CT, int PK>
+TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double (&u)[M]) {
+  if (!K.diag) return dyn_f<M, CT, PK>(C, S, u);
+  State F;
+  const double dt = K.dt;
+  Pose E = se3_exp(dt * S.w, dt * S.v);
+  F.X = se3_project(se3_compose(S.X, E));
+  V3 y1 = v3(K.ib[0] * S.w.x, K.ib[1] * S.w.y, K.ib[2] * S.w.z);
+  V3 y2 = v3(K.jv[0] * S.v.x, K.jv[1] * S.v.y, K.jv[2] * S.v.z);
+  V3 top = cross(y1, S.w) + cross(y2, S.v);
+  V3 bot = cross(y2, S.w);
+  if (PK == 1) {
+    V3 wv = qrot_inv(S.X.q, v3(u[0], u[1], u[2] - C.grav));
+    top = top + v3(C.pend_k * wv.y, -C.pend_k * wv.x, 0.0);
+  } else {
+    if (K.mg != 0.0) bot = bot + K.mg * qrot_inv(S.X.q, v3(0, 0, -1.0));
+    top = top + v3(u[0], u[1], u[2]);
+  }
+  if constexpr (M == 6) bot = bot + v3(u[3], u[4], u[5]);
+  else bot = bot + v3(0, 0, u[3]);
+  F.w = S.w + v3(K.bt[0] * top.x, K.bt[1] * top.y, K.bt[2] * top.z);
+  F.v = S.v + dt * v3(K.jvi[0] * bot.x, K.jvi[1] * bot.y, K.jvi[2] * bot.z);
+  return F;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pack / unpack between the reference's 4x4 AoS layout (C ABI) and the device SoA layout
 // ------------------------------------------------------------------------------------------------
@@ -1315,8 +1360,8 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
 }
 
 template <int M, bool LINEAR, bool ALPHA1, int PK, class CT>
-TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool writer, unsigned vb, unsigned sB,
-                         double alpha, const State& So, const State& Sn) {
+TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
+                         unsigned sB, double alpha, const State& So, const State& Sn) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
   RollIn<M> R;
   roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R);  // in flight while Log runs
@@ -1343,7 +1388,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool
   for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
   State Nx;
   if constexpr (!LINEAR) {
-    State Fn = dyn_f<M, CT, PK>(C, Sn, un);
+    State Fn = dyn_f_k<M, CT, PK>(DK, C, Sn, un);
     Pose Mx;
     V3 cw, cv;
     if constexpr (ALPHA1) {
@@ -1354,7 +1399,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, int i, int b, int q, bool
       double d[12];
 #pragma unroll
       for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
-      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M, CT, PK>(C, So, R.u);
+      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f_k<M, CT, PK>(DK, C, So, R.u);
       Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                        se3_inverse(Fo.X));
       cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
@@ -1406,15 +1451,16 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   } else {
     Sn = load_state_b(mkbuf(P.cand + (size_t)13 * P.Bp * i0, 13 * sB), vb, sB);
   }
+  const DynK DK = dynk_load(C);
   State Sa = roll_load_state(P, i0, vb, sB), Sb = Sa;
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, i, b, q, writer, vb, sB, alpha, Sa, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
   }
 }
 
