@@ -939,8 +939,8 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // Per-lane constant columns (2 W2, 2 R, and the two views of F_u).  They live in LDS, not in 48 VGPRs:
   // the kernel is far over the 256 architectural registers and every value parked in an AGPR costs a
   // v_accvgpr copy per use, while LDS is otherwise idle here.  Row stride 25 doubles: conflict-free.
-  __shared__ double KC[16][25];
-  enum { KC_W2 = 0, KC_R = 6, KC_BLOC = 12, KC_BROW = 18 };
+  __shared__ double KC[16][43];
+  enum { KC_W2 = 0, KC_R = 6, KC_BLOC = 12, KC_BROW = 18, KC_BT = 24, KC_BB = 33 };  // KC_BT/BB: same in every row
   if (g == 0) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -952,6 +952,8 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       KC[j][KC_R + u] = (u < M && j < M) ? 2.0 * C.R[(u < M ? u : 0) * M + j] : 0.0;
       KC[j][KC_BROW + u] = (u < M && j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
     }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = C.Bt[k]; KC[j][KC_BB + k] = C.Bb[k]; }
   }
   __builtin_amdgcn_wave_barrier();
   const double* KCj = KC[j];
@@ -1035,8 +1037,20 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
   };
 
+  // The gains of knot i are stored half a step late, right before the prefetch of step i-1 is issued:
+  // vmcnt is in-order, and with the stores issued at the end of a step the s_waitcnt vmcnt(0) at the
+  // top of the next one (prefetched fields) also waited for their write acknowledgements.
+  double Kst[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) Kst[u] = 0;
+  auto store_gains = [&](int knot) {
+    if (act && j < 13) {
+      __amdgpu_buffer_rsrc_t rGs = mkbuf(P.GK + gStride * knot, 13 * M * sB);
+#pragma unroll
+      for (int u = 0; u < M; u++) bst(rGs, vG, (unsigned)(u * 13) * REC_SR, Kst[u]);
+    }
+  };
   auto step = [&](int i, BwdIn& in) {
-    __amdgpu_buffer_rsrc_t rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
     double A[12], Lc[12], lu[M];
     const double luu_i = in.luu;
 #pragma unroll
@@ -1089,7 +1103,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
     for (int u = 0; u < M; u++) { kR[u] = KCj[KC_R + u]; kBrow[u] = KCj[KC_BROW + u]; }
 #pragma unroll
-    for (int k = 0; k < 9; k++) { cBt[k] = C.Bt[k]; cBb[k] = C.Bb[k]; }
+    for (int k = 0; k < 9; k++) { cBt[k] = KCj[KC_BT + k]; cBb[k] = KCj[KC_BB + k]; }
     // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
     double BtS[VARB ? 9 : 1], BlocS[VARB ? 6 : 1], BrowS[VARB ? M : 1];
     if constexpr (VARB) {
@@ -1105,6 +1119,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       for (int u = 0; u < 3; u++) BrowS[u] = (j == 6) ? BtS[u] : (j == 7) ? BtS[3 + u] : (j == 8) ? BtS[6 + u] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (i < N - 1) store_gains(i + 1);
     if (i > 0) load_knot(i - 1, in);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1216,10 +1231,8 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
 #pragma unroll
     for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
-    if (act && j < 13) {
 #pragma unroll
-      for (int u = 0; u < M; u++) bst(rG, vG, (unsigned)(u * 13) * REC_SR, Kh[u]);
-    }
+    for (int u = 0; u < M; u++) Kst[u] = Kh[u];
     // ---- V <- Qh + Q_ux^T [K | k]   (== Eq. 11b/11c of traopt_controller.py:2998-3003 for the
     // exact gains), then symmetrise the matrix columns through LDS (traopt_controller.py:3004)
     double Vn[12];
@@ -1246,6 +1259,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   BwdIn in;
   load_knot(N - 1, in);
   for (int i = N - 1; i >= 0; i--) step(i, in);
+  store_gains(0);
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
   double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
   if (act && j == 0) {
