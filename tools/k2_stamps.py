@@ -1,0 +1,18 @@
+"""Per-phase cycle stamps of the backward sweep (debug build: hipcc ... -DTOLG_STAMPS, loaded through
+TOLG_HIP_LIB).  Prints s_memtime cycles per knot for each phase of k_backward, wavefront 7."""
+import numpy as np
+import torch
+from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR, workloads
+
+B, N, K = 4096, 200, 12
+prob, x0_q, x0_xi, us0 = workloads.se3_tracking(B, N=N)
+s = BatchedTrackingILQR(prob, B)
+r = s.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0)
+torch.cuda.synchronize()
+st = r.mu_hist[28, :8].cpu().numpy()
+names = ["consume loads, build A/Lc", "Z = V A (144 dpp fmac)", "Qh = L + A^T Z", "const fetch + stores + prefetch issue",
+         "regularise + Q_uu + Cholesky", "gradient + gain solve", "V update + LDS transpose", "epilogue"]
+tot = st[:7].sum()
+for n, v in zip(names, st):
+    print("%-40s %8.0f cycles/knot  %5.1f %%" % (n, v / N, 100 * v / tot))
+print("total per knot %.0f (s_memtime ticks)" % (tot / N))

@@ -1005,6 +1005,12 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
   }
   double gsum = 0;
+#ifdef TOLG_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(k)
+#endif
 
   // Raw loads of one knot (column j of [F_x | d], of [l_xx | l_x], the controls), issued one knot
   // ahead of their use.  Nothing here may consume a loaded value: that would put the wait for the
@@ -1065,6 +1071,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r]; }  // + 2 W2: added to Qh below
 #pragma unroll
     for (int a = 0; a < M; a++) lu[a] = mvec * in.lu[a];  // l_u = 2 R u rides in the vector columns
+    STAMP(0)
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
 #pragma unroll
@@ -1074,6 +1081,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     rank1_bk<0>(Z, V, A[0]); rank1_bk<1>(Z, V, A[1]); rank1_bk<2>(Z, V, A[2]); rank1_bk<3>(Z, V, A[3]);
     rank1_bk<4>(Z, V, A[4]); rank1_bk<5>(Z, V, A[5]); rank1_bk<6>(Z, V, A[6]); rank1_bk<7>(Z, V, A[7]);
     rank1_bk<8>(Z, V, A[8]); rank1_bk<9>(Z, V, A[9]); rank1_bk<10>(Z, V, A[10]); rank1_bk<11>(Z, V, A[11]);
+    STAMP(1)
     // ---- Qh = [l_xx | l_x] + F_x^T Z
     double Qh[12];
 #pragma unroll
@@ -1094,6 +1102,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     // regularisation / Cholesky / gain / V-update half of the step runs.  One buffer instead of a
     // ping-pong pair keeps the loads in VGPRs (with two, the allocator parked them in AGPRs and had to
     // wait for them right away to copy them back).
+    STAMP(2)
     // Constants of the second half, requested BEFORE the prefetch so that their LDS / scalar-cache
     // latency passes while the 31 buffer loads issue (read where they are used, each cost an exposed
     // lgkmcnt(0) wait: ~10 per knot).
@@ -1124,6 +1133,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 6; r++) Qh[6 + r] += kW2[r];
+    STAMP(3)
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
     double Quh[M], Kh[M], Ls[M][M], dinv[M], Qrep[M][M];
     bool use_lu = false;
@@ -1204,6 +1214,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         if (__all(done)) break;
       }
     }
+    STAMP(4)
     // gradient term: ||Q_u|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
     {
       double s = 0;
@@ -1233,6 +1244,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
 #pragma unroll
     for (int u = 0; u < M; u++) Kst[u] = Kh[u];
+    STAMP(5)
     // ---- V <- Qh + Q_ux^T [K | k]   (== Eq. 11b/11c of traopt_controller.py:2998-3003 for the
     // exact gains), then symmetrise the matrix columns through LDS (traopt_controller.py:3004)
     double Vn[12];
@@ -1254,12 +1266,17 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       double vt = (j < 12) ? TR[g][j * 13 + r] : Vn[r];
       V[r] = 0.5 * (Vn[r] + vt);
     }
+    STAMP(6)
   };
 
   BwdIn in;
   load_knot(N - 1, in);
   for (int i = N - 1; i >= 0; i--) step(i, in);
   store_gains(0);
+#ifdef TOLG_STAMPS
+  STAMP(7)
+  if (blockIdx.x == 7 && lane == 0 && P.mu_hist) { for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st_acc[k]; }
+#endif
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
   double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
   if (act && j == 0) {
