@@ -108,6 +108,17 @@ TOLG_DEV double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
 TOLG_DEV void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
 }
+// two neighbouring doubles with one 16-byte access (offsets must be 16-byte aligned)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+TOLG_DEV void bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double& x0, double& x1) {
+  f64x2 v = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  x0 = v.x; x1 = v.y;
+}
+TOLG_DEV void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x0, double x1) {
+  f64x2 v = {x0, x1};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
 // Knot record: everything K2/K3 need from the linearisation, one field per [Bp]-long row so that K1
 // (thread per trajectory, batch fastest) writes fully coalesced and K2's lanes pick the entries of
 // their own column by address.  3x3 blocks are stored column-major (column c at +3c).
@@ -122,27 +133,33 @@ enum {
   REC_LX = 72,   // l_x (12)
   REC_M = 84,    // rollout left factor M = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 (quaternion xyzw, t)
   REC_C = 91,    // rollout offset c = xi_{i+1} - f_xi(x_i,u_i) + d_xi
-  REC_A22 = 97,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
-  REC_LU = 133,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
-  REC_LUU = 139, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
-  REC_F = 145,
+  REC_A22 = 98,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]   (97 is padding: pairs below)
+  REC_LU = 134,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
+  REC_LUU = 140, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
+  REC_F = 146,
   // Pendulum3dDyanmics only: F_u[6:9,0:3] = J^-1 skew(m rho) R^T dt (state dependent), row-major, in the
   // slot of REC_TRI -- that block of F_x is identically zero without a translation, and an extra
   // field would leave a never-written hole in every 4.6 KB record group of all the other models
   REC_BU = REC_TRI
 };
-// Records and gains are interleaved by four trajectories: [knot][b / 4][field][b % 4].  The four
-// trajectories of one K2 wavefront then own one contiguous 4.6 KB run per knot (every 64-byte
-// sector it touches is entirely its own), while K1/K3 (one thread per trajectory) still move whole
-// 32-byte groups.  With the plain [knot][field][Bp] layout K2 fetched every 128-byte line four times.
-#define RIDX(i, f, b) (((size_t)(i)) * REC_F * (size_t)P.Bp + ((((size_t)(b)) >> 2) * REC_F + (size_t)(f)) * 4 + (((size_t)(b)) & 3))
+// Records and gains are interleaved by four trajectories and by field pairs:
+// REC [knot][b / 4][field / 2][b % 4][field % 2], GK [knot][b / 4][column j][row u / 2][b % 4][u % 2].
+// The four trajectories of one K2 wavefront then own one contiguous 4.7 KB run per knot (every 64-byte
+// sector it touches is entirely its own; with a plain [knot][field][Bp] layout K2 fetched every
+// 128-byte line four times), while a thread that owns one trajectory moves two neighbouring fields with
+// one 16-byte access: K1 stores, K2's A22 / l_x / l_u loads and gain stores, K3's gain-row and rollout
+// factor loads.  Runs that are read or written as pairs start on even fields (REC_D, REC_LX, REC_M,
+// REC_A22, REC_LU).  Store-pattern microbenchmark: profiles/r01_store_microbench.txt.
+#define RIDX(i, f, b) \
+  (((size_t)(i)) * REC_F * (size_t)P.Bp + (((size_t)(b)) >> 2) * (REC_F * 4) + (((size_t)(f)) >> 1) * 8 + (((size_t)(b)) & 3) * 2 + (((size_t)(f)) & 1))
 #define GKIDX(i, u, b, j) \
-  (((size_t)(i)) * 13 * (size_t)P.m * (size_t)P.Bp + ((((size_t)(b)) >> 2) * 13 * (size_t)P.m + (size_t)(u) * 13 + (size_t)(j)) * 4 + (((size_t)(b)) & 3))
-// byte offsets for the buffer accessors: field stride and the lane's base inside one knot
-#define REC_SR 32u
-#define REC_VR(b) ((unsigned)((b) >> 2) * (REC_F * 32u) + (unsigned)((b) & 3) * 8u)
-#define GK_VG(b, M_) ((unsigned)((b) >> 2) * (13u * (M_) * 32u) + (unsigned)((b) & 3) * 8u)
-// SO3Dynamics and Pendulum3dDyanmics share the SO3 cost / controller conventions
+  (((size_t)(i)) * 13 * (size_t)P.m * (size_t)P.Bp + (((size_t)(b)) >> 2) * 13 * (size_t)P.m * 4 +    \
+   (((size_t)(j)) * ((size_t)P.m / 2) + (((size_t)(u)) >> 1)) * 8 + (((size_t)(b)) & 3) * 2 + (((size_t)(u)) & 1))
+// byte offsets for the buffer accessors: the lane's base inside one knot, then field / gain-entry offsets
+#define REC_VR(b) ((unsigned)((b) >> 2) * (REC_F * 32u) + (unsigned)((b) & 3) * 16u)
+#define GK_VG(b, M_) ((unsigned)((b) >> 2) * (13u * (M_) * 32u) + (unsigned)((b) & 3) * 16u)
+#define FOFF(f) ((((unsigned)(f)) >> 1) * 64u + (((unsigned)(f)) & 1u) * 8u)
+#define GOFF(u, j, M_) ((((unsigned)(j)) * ((M_) / 2u) + (((unsigned)(u)) >> 1)) * 64u + (((unsigned)(u)) & 1u) * 8u)
 __host__ __device__ inline bool so3_family(int kind) { return kind == TOLG_DYN_SO3 || kind == TOLG_DYN_PENDULUM3D; }
 __host__ __device__ inline int sym6(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
 
@@ -974,12 +991,15 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   const unsigned vr = REC_VR(b);
-  const unsigned vT = vr + (unsigned)fT * REC_SR, vM = vr + (unsigned)fM * REC_SR, vBt = vr + (unsigned)fB * REC_SR;
-  const unsigned vG = GK_VG(b, M) + (unsigned)(j < 13 ? j : 12) * REC_SR;
-  const unsigned vUU = vr + (unsigned)(REC_LUU + (j < M ? j : 0)) * REC_SR;
+  unsigned oT[3], oM[3];  // fT / fM are odd for every second lane: per-row offsets instead of base + r
+#pragma unroll
+  for (int r = 0; r < 3; r++) { oT[r] = vr + FOFF(fT + r); oM[r] = vr + FOFF(fM + r); }
+  const unsigned vBt = vr + FOFF(fB);  // fB is even (REC_A22, REC_D even): rows r, r+1 are one 16-byte pair
+  const unsigned vG = GK_VG(b, M) + GOFF(0, (j < 13 ? j : 12), M);
+  const unsigned vUU = vr + FOFF(REC_LUU + (j < M ? j : 0));
   unsigned vL[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) vL[r] = vr + (unsigned)fL[r] * REC_SR;
+  for (int r = 0; r < 6; r++) vL[r] = vr + FOFF(fL[r]);
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   const double mB = ((j >= 6 && j < 12) || j == 12) ? 1.0 : 0.0;
   double Cg[GRAV ? 3 : 1][6];
@@ -998,7 +1018,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, REC_VR(b), (REC_LX + 6 + r) * REC_SR);
+      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, REC_VR(b), FOFF(REC_LX + 6 + r));
       V[r] = mLT * t1;
       double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
       V[6 + r] = mvec * t2 + p2;
@@ -1020,26 +1040,25 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      in.t[r] = bld(rR, vT, r * REC_SR);
-      in.m[r] = bld(rR, vM, r * REC_SR);
+      in.t[r] = bld(rR, oT[r], 0);
+      in.m[r] = bld(rR, oM[r], 0);
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) in.bt[r] = bld(rR, vBt, r * REC_SR);
+    for (int r = 0; r < 6; r += 2) bld2(rR, vBt, FOFF(r), in.bt[r], in.bt[r + 1]);
     if constexpr (GRAV) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), (REC_RTE + a) * REC_SR);
+      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), FOFF(REC_RTE + a));
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      in.lt[r] = bld(rR, vL[r], 0);
-      in.lb[r] = bld(rR, REC_VR(b), (REC_LX + 6 + r) * REC_SR);
-    }
+    for (int r = 0; r < 6; r++) in.lt[r] = bld(rR, vL[r], 0);
 #pragma unroll
-    for (int a = 0; a < M; a++) in.lu[a] = bld(rR, REC_VR(b), (REC_LU + a) * REC_SR);
+    for (int r = 0; r < 6; r += 2) bld2(rR, REC_VR(b), FOFF(REC_LX + 6 + r), in.lb[r], in.lb[r + 1]);
+#pragma unroll
+    for (int a = 0; a < M; a += 2) bld2(rR, REC_VR(b), FOFF(REC_LU + a), in.lu[a], in.lu[a + 1]);
     in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
     if constexpr (VARB) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) in.bu[k] = bld(rR, REC_VR(b), (REC_BU + k) * REC_SR);
+      for (int k = 0; k < 9; k++) in.bu[k] = bld(rR, REC_VR(b), FOFF(REC_BU + k));
     }
   };
 
@@ -1053,7 +1072,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     if (act && j < 13) {
       __amdgpu_buffer_rsrc_t rGs = mkbuf(P.GK + gStride * knot, 13 * M * sB);
 #pragma unroll
-      for (int u = 0; u < M; u++) bst(rGs, vG, (unsigned)(u * 13) * REC_SR, Kst[u]);
+      for (int u = 0; u < M; u += 2) bst2(rGs, vG, GOFF(u, 0, M), Kst[u], Kst[u + 1]);
     }
   };
   auto step = [&](int i, BwdIn& in) {
@@ -1355,7 +1374,7 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
 // while Log runs.  A few hundred waves cannot hide memory latency any other way.
 template <int M>
 struct RollIn {
-  double G[2][13];   // gain rows q and q + 4 of [K | k]
+  double G[2][13];   // gain rows 2q and 2q + 1 of [K | k] (one 16-byte pair per column)
   double u[M];
   Pose Mx;           // REC_M
   V3 cw, cv;         // REC_C
@@ -1372,21 +1391,22 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
   __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
-  const unsigned vg0 = GK_VG(b, M) + (unsigned)(q * 13) * REC_SR;
-  const unsigned vg1 = GK_VG(b, M) + (unsigned)(((q + 4 < M) ? q + 4 : q) * 13) * REC_SR;  // M = 4: second row unused
+  const int qp = (2 * q < M) ? q : M / 2 - 1;  // lanes past the last row pair re-read it (their product is unused)
+  const unsigned vg = GK_VG(b, M) + GOFF(2 * qp, 0, M);
 #pragma unroll
-  for (int k = 0; k < 13; k++) {
-    R.G[0][k] = bld(rG, vg0, (unsigned)k * REC_SR);
-    R.G[1][k] = bld(rG, vg1, (unsigned)k * REC_SR);
-  }
+  for (int k = 0; k < 13; k++) bld2(rG, vg, GOFF(0, k, M), R.G[0][k], R.G[1][k]);
 #pragma unroll
   for (int a = 0; a < M; a++) R.u[a] = bld(rU, vb, a * sB);
   if constexpr (ALPHA1) {
-    R.Mx.q.x = bld(rR, REC_VR(b), (REC_M + 0) * REC_SR); R.Mx.q.y = bld(rR, REC_VR(b), (REC_M + 1) * REC_SR);
-    R.Mx.q.z = bld(rR, REC_VR(b), (REC_M + 2) * REC_SR); R.Mx.q.w = bld(rR, REC_VR(b), (REC_M + 3) * REC_SR);
-    R.Mx.t = v3(bld(rR, REC_VR(b), (REC_M + 4) * REC_SR), bld(rR, REC_VR(b), (REC_M + 5) * REC_SR), bld(rR, REC_VR(b), (REC_M + 6) * REC_SR));
-    R.cw = v3(bld(rR, REC_VR(b), (REC_C + 0) * REC_SR), bld(rR, REC_VR(b), (REC_C + 1) * REC_SR), bld(rR, REC_VR(b), (REC_C + 2) * REC_SR));
-    R.cv = v3(bld(rR, REC_VR(b), (REC_C + 3) * REC_SR), bld(rR, REC_VR(b), (REC_C + 4) * REC_SR), bld(rR, REC_VR(b), (REC_C + 5) * REC_SR));
+    // REC_M (7) and REC_C (6) are 13 consecutive fields from an even one: seven 16-byte loads
+    static_assert(REC_M % 2 == 0 && REC_C == REC_M + 7, "rollout factors must start on a field pair");
+    double f[14];
+#pragma unroll
+    for (int k = 0; k < 14; k += 2) bld2(rR, REC_VR(b), FOFF(REC_M + k), f[k], f[k + 1]);
+    R.Mx.q.x = f[0]; R.Mx.q.y = f[1]; R.Mx.q.z = f[2]; R.Mx.q.w = f[3];
+    R.Mx.t = v3(f[4], f[5], f[6]);
+    R.cw = v3(f[7], f[8], f[9]);
+    R.cv = v3(f[10], f[11], f[12]);
   }
 }
 
@@ -1412,9 +1432,9 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
     mine[sidx] = sacc;
   }
   double un[M], du[M];
-  du[0] = quad_bcast<0>(mine[0]); du[1] = quad_bcast<1>(mine[0]);
-  du[2] = quad_bcast<2>(mine[0]); du[3] = quad_bcast<3>(mine[0]);
-  if constexpr (M == 6) { du[4] = quad_bcast<0>(mine[1]); du[5] = quad_bcast<1>(mine[1]); }
+  du[0] = quad_bcast<0>(mine[0]); du[1] = quad_bcast<0>(mine[1]);
+  du[2] = quad_bcast<1>(mine[0]); du[3] = quad_bcast<1>(mine[1]);
+  if constexpr (M == 6) { du[4] = quad_bcast<2>(mine[0]); du[5] = quad_bcast<2>(mine[1]); }
 #pragma unroll
   for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
   State Nx;
@@ -1429,7 +1449,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
       __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
       double d[12];
 #pragma unroll
-      for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
+      for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
       State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f_k<M, CT, PK>(DK, C, So, R.u);
       Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                        se3_inverse(Fo.X));
@@ -1444,7 +1464,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
     double lin[12], d[12];
     fx_apply<M>(P, *P.c, i, b, e, du, lin);
 #pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
+    for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), FOFF(REC_D + a));
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
     Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
     Nx.X = se3_project(se3_compose(Sx.X, D));
@@ -1573,9 +1593,9 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
     double u[M], un[M], du[M];
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double sacc = alpha * bld(rG, GK_VG(b, M), (unsigned)(a * 13 + 12) * REC_SR);
+      double sacc = alpha * bld(rG, GK_VG(b, M), GOFF(a, 12, M));
 #pragma unroll
-      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), (unsigned)(a * 13 + k) * REC_SR) * e[k];
+      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), GOFF(a, k, M)) * e[k];
       u[a] = bld(rU, vb, a * sB);
       du[a] = sacc;
       un[a] = u[a] + sacc;
@@ -1587,7 +1607,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
       if constexpr (MS) {
         double d[12];
 #pragma unroll
-        for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
+        for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
         State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, u);
         Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
                               se3_inverse(Fo.X));
@@ -1607,7 +1627,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
       double lin[12], d[12];
       fx_apply<M>(P, C, i, b, e, du, lin);
 #pragma unroll
-      for (int a = 0; a < 12; a++) d[a] = MS ? alpha * bld(rR, REC_VR(b), (REC_D + a) * REC_SR) : 0.0;
+      for (int a = 0; a < 12; a++) d[a] = MS ? alpha * bld(rR, REC_VR(b), FOFF(REC_D + a)) : 0.0;
       State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
       Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
       Nx.X = se3_project(se3_compose(Sx.X, D));
@@ -1657,12 +1677,12 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
     // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
     const double* W2 = (i == N) ? C.P2 : C.W2;
 #pragma unroll
-    for (int a = 0; a < 12; a++) c1 += bld(rR, REC_VR(b), (REC_LX + a) * REC_SR) * e[a];
+    for (int a = 0; a < 12; a++) c1 += bld(rR, REC_VR(b), FOFF(REC_LX + a)) * e[a];
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        c2 += e[a] * bld(rR, REC_VR(b), (unsigned)(REC_LXX + sym6(a, k)) * REC_SR) * e[k];
+        c2 += e[a] * bld(rR, REC_VR(b), FOFF(REC_LXX + sym6(a, k))) * e[k];
         c2 += e[6 + a] * 2.0 * W2[6 * a + k] * e[6 + k];
       }
     if (i == N) break;
@@ -1670,22 +1690,22 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
     double du[M];
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double sacc = bld(rG, GK_VG(b, M), (unsigned)(a * 13 + 12) * REC_SR);
+      double sacc = bld(rG, GK_VG(b, M), GOFF(a, 12, M));
 #pragma unroll
-      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), (unsigned)(a * 13 + k) * REC_SR) * e[k];
+      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), GOFF(a, k, M)) * e[k];
       du[a] = sacc;
     }
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      c1 += bld(rR, REC_VR(b), (REC_LU + a) * REC_SR) * du[a];
+      c1 += bld(rR, REC_VR(b), FOFF(REC_LU + a)) * du[a];
 #pragma unroll
       for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
-      c2 += du[a] * bld(rR, REC_VR(b), (REC_LUU + a) * REC_SR) * du[a];
+      c2 += du[a] * bld(rR, REC_VR(b), FOFF(REC_LUU + a)) * du[a];
     }
     double lin[12], d[12];
     fx_apply<M>(P, C, i, b, e, du, lin);
 #pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), (REC_D + a) * REC_SR);
+    for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
     Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
     Sn.X = se3_project(se3_compose(Sx.X, D));
