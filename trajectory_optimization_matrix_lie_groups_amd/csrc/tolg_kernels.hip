@@ -412,6 +412,19 @@ __global__ void k_init_rollout(Params P) {
   }
 }
 
+// N consecutive record fields from F0, as 16-byte stores wherever a field pair is complete
+template <int F0, int N>
+TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
+  constexpr int H = F0 & 1;  // an odd first field goes alone
+  if constexpr (H) P.REC[RIDX(i, F0, b)] = v[0];
+#pragma unroll
+  for (int k = H; k + 1 < N; k += 2) {
+    f64x2 w = {v[k], v[k + 1]};
+    *reinterpret_cast<f64x2*>(&P.REC[RIDX(i, F0 + k, b)]) = w;
+  }
+  if constexpr (((N - H) & 1) != 0) P.REC[RIDX(i, F0 + N - 1, b)] = v[N - 1];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: linearisation, one thread per (trajectory, knot)
 // ------------------------------------------------------------------------------------------------
@@ -482,8 +495,10 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         Je[6 * (a + 3) + c + 3] = Ja[3 * a + c];
       }
     if (ms == 2) {
+      double ed[12];
 #pragma unroll
-      for (int a = 0; a < 6; a++) { P.REC[RIDX(i, REC_D + a, b)] = e[a]; P.REC[RIDX(i, REC_D + 6 + a, b)] = ve[a]; }
+      for (int a = 0; a < 6; a++) { ed[a] = e[a]; ed[6 + a] = ve[a]; }
+      rec_run<REC_D, 12>(P, i, b, ed);
     }
     double We[6], W2v[6], l = 0;
 #pragma unroll
@@ -524,11 +539,8 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
           luu[a] = imu[a] + imu[M + a];
         }
       }
-#pragma unroll
-      for (int a = 0; a < M; a++) {
-        P.REC[RIDX(i, REC_LU + a, b)] = lu[a];
-        P.REC[RIDX(i, REC_LUU + a, b)] = luu[a];
-      }
+      rec_run<REC_LU, M>(P, i, b, lu);
+      rec_run<REC_LUU, M>(P, i, b, luu);
     }
     P.SC[(size_t)i * P.Bp + b] = l;
     double WJ[36];
@@ -541,6 +553,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         for (int k = 0; k < 6; k++) s += W1[6 * a + k] * Je[6 * k + c];
         WJ[6 * a + c] = s;
       }
+    double lxx[21], lxv[12];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -548,14 +561,16 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         double s = 0, s2 = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) { s += Je[6 * k + a] * WJ[6 * k + c]; s2 += Je[6 * k + c] * WJ[6 * k + a]; }
-        P.REC[RIDX(i, REC_LXX + sym6(a, c), b)] = s + s2;  // == 2 * symmetric part
+        lxx[sym6(a, c)] = s + s2;  // == 2 * symmetric part
       }
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) s += Je[6 * k + a] * We[k];
-      P.REC[RIDX(i, REC_LX + a, b)] = 2 * s;
-      P.REC[RIDX(i, REC_LX + 6 + a, b)] = 2 * W2v[a];
+      lxv[a] = 2 * s;
+      lxv[6 + a] = 2 * W2v[a];
     }
+    rec_run<REC_LXX, 21>(P, i, b, lxx);
+    rec_run<REC_LX, 12>(P, i, b, lxv);
   }
   if (term) return;
   // ---------------- dynamics Jacobian blocks (traopt_dynamics.py:802-837, :1416-1469)
@@ -575,15 +590,25 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     double Jr3[9], Qr[9];
     ljac33(neg(wd), kc, Jr3);
     Q33(neg(vd), neg(wd), kc, Qr);
+    static_assert(REC_RI == 0 && REC_TRI == 9 && REC_JR == 18 && REC_QR == 27, "the four pose blocks form one run");
+    double blk[36];
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        P.REC[RIDX(i, REC_RI + 3 * c + a, b)] = Ri[3 * a + c];
-        if (C.kind != TOLG_DYN_PENDULUM3D) P.REC[RIDX(i, REC_TRI + 3 * c + a, b)] = TR[3 * a + c];  // else: REC_BU
-        P.REC[RIDX(i, REC_JR + 3 * c + a, b)] = dt * Jr3[3 * a + c];
-        P.REC[RIDX(i, REC_QR + 3 * c + a, b)] = dt * Qr[3 * a + c];
+        blk[REC_RI + 3 * c + a] = Ri[3 * a + c];
+        blk[REC_TRI + 3 * c + a] = TR[3 * a + c];
+        blk[REC_JR + 3 * c + a] = dt * Jr3[3 * a + c];
+        blk[REC_QR + 3 * c + a] = dt * Qr[3 * a + c];
       }
+    if (C.kind == TOLG_DYN_PENDULUM3D) {  // the REC_TRI slot is REC_BU there (written below), the block is zero
+#pragma unroll
+      for (int k = 0; k < 9; k++) P.REC[RIDX(i, REC_RI + k, b)] = blk[k];
+#pragma unroll
+      for (int k = 18; k < 36; k++) P.REC[RIDX(i, k, b)] = blk[k];
+    } else {
+      rec_run<0, 36>(P, i, b, blk);
+    }
   }
   {
     // A22 = I + H dt, H = J^-1 (coadjoint([v, w]) J + G)  <- literal swapped twist (App. C-Q1)
@@ -611,16 +636,18 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
     mul33(C.Ibinv, M12, H12);
     mul33(C.Jvinv, M21, H21);
     mul33(C.Jvinv, M22, H22);
+    double a22[36];
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         double id = (r == c) ? 1.0 : 0.0;
-        P.REC[RIDX(i, REC_A22 + 6 * c + r, b)] = id + dt * H11[3 * r + c];
-        P.REC[RIDX(i, REC_A22 + 6 * (c + 3) + r, b)] = dt * H12[3 * r + c];
-        P.REC[RIDX(i, REC_A22 + 6 * c + r + 3, b)] = dt * H21[3 * r + c];
-        P.REC[RIDX(i, REC_A22 + 6 * (c + 3) + r + 3, b)] = id + dt * H22[3 * r + c];
+        a22[6 * c + r] = id + dt * H11[3 * r + c];
+        a22[6 * (c + 3) + r] = dt * H12[3 * r + c];
+        a22[6 * c + r + 3] = dt * H21[3 * r + c];
+        a22[6 * (c + 3) + r + 3] = id + dt * H22[3 * r + c];
       }
+    rec_run<REC_A22, 36>(P, i, b, a22);
   }
   {
     V3 rte = (C.grav != 0.0) ? qrot_inv(S.X.q, v3(0, 0, -1.0)) : v3(0, 0, 0);
@@ -641,9 +668,8 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 #pragma unroll
       for (int k = 0; k < 9; k++) P.REC[RIDX(i, REC_BU + k, b)] = dt * Bu[k];
     }
-    P.REC[RIDX(i, REC_RTE + 0, b)] = rte.x;
-    P.REC[RIDX(i, REC_RTE + 1, b)] = rte.y;
-    P.REC[RIDX(i, REC_RTE + 2, b)] = rte.z;
+    const double rt[3] = {rte.x, rte.y, rte.z};
+    rec_run<REC_RTE, 3>(P, i, b, rt);
   }
   // ---------------- defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}]  (traopt_controller.py:2882-2888)
   // and the rollout factors of traopt_controller.py:2713-2716 for alpha = 1
@@ -652,11 +678,8 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   V3 cw, cv;
   if (ms == 2) {  // probe: export f(x, u) itself
     State F = dyn_f<M>(C, S, u);
-    P.REC[RIDX(i, REC_M + 0, b)] = F.X.q.x; P.REC[RIDX(i, REC_M + 1, b)] = F.X.q.y;
-    P.REC[RIDX(i, REC_M + 2, b)] = F.X.q.z; P.REC[RIDX(i, REC_M + 3, b)] = F.X.q.w;
-    P.REC[RIDX(i, REC_M + 4, b)] = F.X.t.x; P.REC[RIDX(i, REC_M + 5, b)] = F.X.t.y; P.REC[RIDX(i, REC_M + 6, b)] = F.X.t.z;
-    P.REC[RIDX(i, REC_C + 0, b)] = F.w.x; P.REC[RIDX(i, REC_C + 1, b)] = F.w.y; P.REC[RIDX(i, REC_C + 2, b)] = F.w.z;
-    P.REC[RIDX(i, REC_C + 3, b)] = F.v.x; P.REC[RIDX(i, REC_C + 4, b)] = F.v.y; P.REC[RIDX(i, REC_C + 5, b)] = F.v.z;
+    const double mc[13] = {F.X.q.x, F.X.q.y, F.X.q.z, F.X.q.w, F.X.t.x, F.X.t.y, F.X.t.z, F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
+    rec_run<REC_M, 13>(P, i, b, mc);
     return;
   }
   if (ms) {
@@ -678,16 +701,11 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   }
   double d2 = 0;
 #pragma unroll
-  for (int a = 0; a < 12; a++) {
-    P.REC[RIDX(i, REC_D + a, b)] = d[a];
-    d2 += d[a] * d[a];
-  }
+  for (int a = 0; a < 12; a++) d2 += d[a] * d[a];
+  rec_run<REC_D, 12>(P, i, b, d);
   P.SD[(size_t)i * P.Bp + b] = d2;
-  P.REC[RIDX(i, REC_M + 0, b)] = Mx.q.x; P.REC[RIDX(i, REC_M + 1, b)] = Mx.q.y;
-  P.REC[RIDX(i, REC_M + 2, b)] = Mx.q.z; P.REC[RIDX(i, REC_M + 3, b)] = Mx.q.w;
-  P.REC[RIDX(i, REC_M + 4, b)] = Mx.t.x; P.REC[RIDX(i, REC_M + 5, b)] = Mx.t.y; P.REC[RIDX(i, REC_M + 6, b)] = Mx.t.z;
-  P.REC[RIDX(i, REC_C + 0, b)] = cw.x; P.REC[RIDX(i, REC_C + 1, b)] = cw.y; P.REC[RIDX(i, REC_C + 2, b)] = cw.z;
-  P.REC[RIDX(i, REC_C + 3, b)] = cv.x; P.REC[RIDX(i, REC_C + 4, b)] = cv.y; P.REC[RIDX(i, REC_C + 5, b)] = cv.z;
+  const double mc[13] = {Mx.q.x, Mx.q.y, Mx.q.z, Mx.q.w, Mx.t.x, Mx.t.y, Mx.t.z, cw.x, cw.y, cw.z, cv.x, cv.y, cv.z};
+  rec_run<REC_M, 13>(P, i, b, mc);
 }
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
