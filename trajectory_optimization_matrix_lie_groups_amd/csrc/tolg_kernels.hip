@@ -969,23 +969,27 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 
   // lane-dependent constants
   const double m12 = (j < 12) ? 1.0 : 0.0;                  // matrix columns
+  const double mW2 = (j >= 6 && j < 12) ? 1.0 : 0.0;        // columns of the velocity block (2 W2 lives there)
   const double mvec = (j == 12 || j == 13) ? 1.0 : 0.0;     // vector columns (V_x, SS adjoint)
   constexpr bool grav = GRAV;
   // Per-lane constant columns (2 W2, 2 R, and the two views of F_u).  They live in LDS, not in 48 VGPRs:
   // the kernel is far over the 256 architectural registers and every value parked in an AGPR costs a
   // v_accvgpr copy per use, while LDS is otherwise idle here.  Row stride 25 doubles: conflict-free.
-  __shared__ double KC[16][43];
-  enum { KC_W2 = 0, KC_R = 6, KC_BLOC = 12, KC_BROW = 18, KC_BT = 24, KC_BB = 33 };  // KC_BT/BB: same in every row
+  __shared__ double KC[16][31];
+  // Lanes 0..M-1 and lanes 6..11 need different constants and never look at each other's: one slot
+  // holds 2R (lanes < M) or the row view of F_u (lanes 6..11), the other the column view of F_u (lanes
+  // < M) or 2 W2 (lanes 6..11).  Where a lane reads the "wrong" half the result is never used, except
+  // in the l_xx update, which masks it.
+  enum { KC_RB = 0, KC_BW = 6, KC_BT = 12, KC_BB = 21 };  // KC_BT/BB: same in every row
   if (g == 0) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      KC[j][KC_W2 + r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
-      KC[j][KC_BLOC + r] = (j < M) ? fu_entry<M>(C, r, j) : 0.0;          // B[6+r][j]
+      KC[j][KC_BW + r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : (j < M) ? fu_entry<M>(C, r, j) : 0.0;  // B[6+r][j]
     }
 #pragma unroll
     for (int u = 0; u < 6; u++) {
-      KC[j][KC_R + u] = (u < M && j < M) ? 2.0 * C.R[(u < M ? u : 0) * M + j] : 0.0;
-      KC[j][KC_BROW + u] = (u < M && j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
+      KC[j][KC_RB + u] = (u < M && j < M) ? 2.0 * C.R[(u < M ? u : 0) * M + j]
+                         : (u < M && j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = C.Bt[k]; KC[j][KC_BB + k] = C.Bb[k]; }
@@ -1143,11 +1147,11 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     // Constants of the second half, requested BEFORE the prefetch so that their LDS / scalar-cache
     // latency passes while the 31 buffer loads issue (read where they are used, each cost an exposed
     // lgkmcnt(0) wait: ~10 per knot).
-    double kW2[6], kR[M], kBloc[6], kBrow[M], cBt[9], cBb[9];
+    double kBW[6], kRB[M], cBt[9], cBb[9];
 #pragma unroll
-    for (int r = 0; r < 6; r++) { kW2[r] = KCj[KC_W2 + r]; kBloc[r] = KCj[KC_BLOC + r]; }
+    for (int r = 0; r < 6; r++) kBW[r] = KCj[KC_BW + r];
 #pragma unroll
-    for (int u = 0; u < M; u++) { kR[u] = KCj[KC_R + u]; kBrow[u] = KCj[KC_BROW + u]; }
+    for (int u = 0; u < M; u++) kRB[u] = KCj[KC_RB + u];
 #pragma unroll
     for (int k = 0; k < 9; k++) { cBt[k] = KCj[KC_BT + k]; cBb[k] = KCj[KC_BB + k]; }
     // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
@@ -1156,9 +1160,9 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
       for (int k = 0; k < 9; k++) BtS[k] = in.bu[k];
 #pragma unroll
-      for (int r = 0; r < 6; r++) BlocS[r] = kBloc[r];
+      for (int r = 0; r < 6; r++) BlocS[r] = kBW[r];
 #pragma unroll
-      for (int u = 0; u < M; u++) BrowS[u] = kBrow[u];
+      for (int u = 0; u < M; u++) BrowS[u] = kRB[u];
 #pragma unroll
       for (int r = 0; r < 3; r++) BlocS[r] = (j == 0) ? BtS[3 * r] : (j == 1) ? BtS[3 * r + 1] : (j == 2) ? BtS[3 * r + 2] : 0.0;
 #pragma unroll
@@ -1169,7 +1173,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     if (i > 0) load_knot(i - 1, in);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 6; r++) Qh[6 + r] += kW2[r];
+    for (int r = 0; r < 6; r++) Qh[6 + r] += mW2 * kBW[r];
     STAMP(3)
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
     double Quh[M], Kh[M], Ls[M][M], dinv[M], Qrep[M][M];
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       double T[M];
 #pragma unroll
       for (int u = 0; u < M; u++) {  // B2 is block diagonal: inputs 0..2 see rows 6..8, the rest rows 9..11
-        double s = lu[u], tt = muA * (VARB ? BrowS[VARB ? u : 0] : kBrow[u]);
+        double s = lu[u], tt = muA * (VARB ? BrowS[VARB ? u : 0] : kRB[u]);
         const int k0 = (u < 3) ? 0 : 3;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -1199,14 +1203,14 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
       double Quu[M];
 #pragma unroll
-      for (int u = 0; u < M; u++) Quu[u] = kR[u] + ((j == u) ? luu_i : 0.0);
+      for (int u = 0; u < M; u++) Quu[u] = kRB[u] + ((j == u) ? luu_i : 0.0);
       if constexpr (VARB) {
         quu_acc<M, 6>(Quu, T, BlocS[0]); quu_acc<M, 7>(Quu, T, BlocS[1]); quu_acc<M, 8>(Quu, T, BlocS[2]);
         quu_acc<M, 9>(Quu, T, BlocS[3 % (VARB ? 6 : 1)]); quu_acc<M, 10>(Quu, T, BlocS[4 % (VARB ? 6 : 1)]);
         quu_acc<M, 11>(Quu, T, BlocS[5 % (VARB ? 6 : 1)]);
       } else {
-        quu_acc<M, 6>(Quu, T, kBloc[0]); quu_acc<M, 7>(Quu, T, kBloc[1]); quu_acc<M, 8>(Quu, T, kBloc[2]);
-        quu_acc<M, 9>(Quu, T, kBloc[3]); quu_acc<M, 10>(Quu, T, kBloc[4]); quu_acc<M, 11>(Quu, T, kBloc[5]);
+        quu_acc<M, 6>(Quu, T, kBW[0]); quu_acc<M, 7>(Quu, T, kBW[1]); quu_acc<M, 8>(Quu, T, kBW[2]);
+        quu_acc<M, 9>(Quu, T, kBW[3]); quu_acc<M, 10>(Quu, T, kBW[4]); quu_acc<M, 11>(Quu, T, kBW[5]);
       }
       // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
       // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
