@@ -957,7 +957,9 @@ TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
 // VARB: F_u differs from knot to knot (Pendulum3dDyanmics): its 3x3 block is read from REC_BU.
 // GRAV: the model has a gravity block A21 in F_x (Drone / RigidBody / Pendulum); SE3 / SO3 instantiate
 // without it and save its 18 per-lane coefficients (36 VGPRs in a kernel that already spills to AGPRs).
-template <int M, bool VARB = false, bool GRAV = true>
+// DIAGJ: I_b and J_v are diagonal (every reference script): F_u's two 3x3 blocks are diagonal (the drone's
+// J_v^-1 e_z column has one entry), so each input touches one row of (V + mu I) F_x instead of three.
+template <int M, bool VARB = false, bool GRAV = true, bool DIAGJ = false>
 __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
@@ -1153,7 +1155,10 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
     for (int u = 0; u < M; u++) kRB[u] = KCj[KC_RB + u];
 #pragma unroll
-    for (int k = 0; k < 9; k++) { cBt[k] = KCj[KC_BT + k]; cBb[k] = KCj[KC_BB + k]; }
+    for (int k = 0; k < 9; k++) {
+      if (DIAGJ && k != 0 && k != 4 && k != 8 && !(M == 4 && k == 6)) { cBt[k] = 0; cBb[k] = 0; continue; }
+      cBt[k] = KCj[KC_BT + k]; cBb[k] = KCj[KC_BB + k];
+    }
     // this knot's input matrix (VARB): the 3x3 block of REC_BU for inputs 0..2 in place of the constants
     double BtS[VARB ? 9 : 1], BlocS[VARB ? 6 : 1], BrowS[VARB ? M : 1];
     if constexpr (VARB) {
@@ -1193,6 +1198,8 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         const int k0 = (u < 3) ? 0 : 3;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
+          // the only row a diagonal block couples to input u (the dense pendulum block keeps all three)
+          if (DIAGJ && !(VARB && u < 3) && k != ((u < 3) ? u : (M == 6 ? u - 3 : 2))) continue;
           const double bku = (u < 3) ? (VARB ? BtS[VARB ? 3 * k + u : 0] : cBt[3 * k + u]) : cBb[3 * k + (u - 3)];
           s += bku * Xp[k0 + k];
           tt += bku * V[6 + k0 + k];
@@ -2303,12 +2310,18 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   Timed t(h, st, 0);
-  if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
-    hipLaunchKernelGGL((k_backward<6, true, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
-  else if (M == 6 && h->hc.grav == 0.0)
-    hipLaunchKernelGGL((k_backward<6, false, false>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
-  else
-    hipLaunchKernelGGL((k_backward<M, false, true>), dim3(P.Bp / 4), dim3(64), 0, st, P, it, ms);
+  const bool dj = h->hc.diagJ != 0;
+  const dim3 grid(P.Bp / 4), blk(64);
+  if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
+    if (dj) hipLaunchKernelGGL((k_backward<6, true, true, true>), grid, blk, 0, st, P, it, ms);
+    else hipLaunchKernelGGL((k_backward<6, true, true, false>), grid, blk, 0, st, P, it, ms);
+  } else if (M == 6 && h->hc.grav == 0.0) {
+    if (dj) hipLaunchKernelGGL((k_backward<6, false, false, true>), grid, blk, 0, st, P, it, ms);
+    else hipLaunchKernelGGL((k_backward<6, false, false, false>), grid, blk, 0, st, P, it, ms);
+  } else {
+    if (dj) hipLaunchKernelGGL((k_backward<M, false, true, true>), grid, blk, 0, st, P, it, ms);
+    else hipLaunchKernelGGL((k_backward<M, false, true, false>), grid, blk, 0, st, P, it, ms);
+  }
   LAUNCH_CHECK();
   return 0;
 }
