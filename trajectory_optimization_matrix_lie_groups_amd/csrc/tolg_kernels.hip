@@ -807,6 +807,15 @@ TOLG_DEV void rank1_bk(double (&acc)[12], const double (&Pm)[12], double q) {
 }
 #endif
 
+// x of the lane six to the right in the same 16-lane row (0 past the row end).  64-bit DPP exists only for
+// row_newbcast: the shift is done on the two halves (the type-generic builtin on a double converted the
+// result numerically here).
+TOLG_DEV double row_shl6(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x106, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x106, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <int L>
 TOLG_DEV double bcast(double x) {  // value of x in lane L of this 16-lane row
   return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, false);
@@ -982,7 +991,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // holds 2R (lanes < M) or the row view of F_u (lanes 6..11), the other the column view of F_u (lanes
   // < M) or 2 W2 (lanes 6..11).  Where a lane reads the "wrong" half the result is never used, except
   // in the l_xx update, which masks it.
-  enum { KC_RB = 0, KC_BW = 6, KC_BT = 12, KC_BB = 21 };  // KC_BT/BB: same in every row
+  enum { KC_RB = 0, KC_BW = 6, KC_BT = 12, KC_BB = 21, KC_BD = 30 };  // KC_BT/BB: same in every row; KC_BD: B[6+j][j]
   if (g == 0) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -995,6 +1004,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = C.Bt[k]; KC[j][KC_BB + k] = C.Bb[k]; }
+    KC[j][KC_BD] = (j < M) ? fu_entry<M>(C, j < 6 ? j : 0, j) : 0.0;
   }
   __builtin_amdgcn_wave_barrier();
   const double* KCj = KC[j];
@@ -1150,6 +1160,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     // latency passes while the 31 buffer loads issue (read where they are used, each cost an exposed
     // lgkmcnt(0) wait: ~10 per knot).
     double kBW[6], kRB[M], cBt[9], cBb[9];
+    const double kBd = KCj[KC_BD];
 #pragma unroll
     for (int r = 0; r < 6; r++) kBW[r] = KCj[KC_BW + r];
 #pragma unroll
@@ -1211,7 +1222,13 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       double Quu[M];
 #pragma unroll
       for (int u = 0; u < M; u++) Quu[u] = kRB[u] + ((j == u) ? luu_i : 0.0);
-      if constexpr (VARB) {
+      if constexpr (DIAGJ && M == 6 && !VARB) {
+        // diagonal F_u blocks: column j of B has the single entry B[6+j][j], so (T B)[u][j] is T[u] of lane
+        // j + 6 times that entry -- one row shift (DPP row_shl:6) and one FMA per input instead of six
+        // broadcast blocks
+#pragma unroll
+        for (int u = 0; u < M; u++) Quu[u] = fma(row_shl6(T[u]), kBd, Quu[u]);
+      } else if constexpr (VARB) {
         quu_acc<M, 6>(Quu, T, BlocS[0]); quu_acc<M, 7>(Quu, T, BlocS[1]); quu_acc<M, 8>(Quu, T, BlocS[2]);
         quu_acc<M, 9>(Quu, T, BlocS[3 % (VARB ? 6 : 1)]); quu_acc<M, 10>(Quu, T, BlocS[4 % (VARB ? 6 : 1)]);
         quu_acc<M, 11>(Quu, T, BlocS[5 % (VARB ? 6 : 1)]);
