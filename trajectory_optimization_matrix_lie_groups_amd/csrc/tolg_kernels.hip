@@ -278,7 +278,7 @@ TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double 
   if (!K.diag) return dyn_f<M, CT, PK>(C, S, u);
   State F;
   const double dt = K.dt;
-  Pose E = se3_exp(dt * S.w, dt * S.v);
+  Pose E = se3_exp_fast(dt * S.w, dt * S.v);
   F.X = se3_project(se3_compose(S.X, E));
   V3 y1 = v3(K.ib[0] * S.w.x, K.ib[1] * S.w.y, K.ib[2] * S.w.z);
   V3 y2 = v3(K.jv[0] * S.v.x, K.jv[1] * S.v.y, K.jv[2] * S.v.z);
@@ -1456,19 +1456,32 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
   }
 }
 
+#ifdef TOLG_STAMPS
+struct RStamps { unsigned long long acc[8], t; };
+#define RSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); ST.acc[k] += t_ - ST.t; ST.t = t_; __builtin_amdgcn_sched_barrier(0); }
+#define RST_PARAM , RStamps& ST
+#define RST_ARG , ST
+#else
+#define RSTAMP(k)
+#define RST_PARAM
+#define RST_ARG
+#endif
 template <int M, bool LINEAR, bool ALPHA1, int PK, class CT>
 TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
-                         unsigned sB, double alpha, const State& So, const State& Sn) {
+                         unsigned sB, double alpha, const State& So, const State& Sn RST_PARAM) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
+  RSTAMP(0)
   RollIn<M> R;
   roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R);  // in flight while Log runs
   __builtin_amdgcn_sched_barrier(0);
+  RSTAMP(1)
   // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
   V3 ew, ev;
-  se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+  se3_log_fast(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
   double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
                   Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
   // du = alpha k + K dx: this lane's two rows, then quad broadcast (identical bits in all four lanes)
+  RSTAMP(2)
   double mine[2];
 #pragma unroll
   for (int sidx = 0; sidx < 2; sidx++) {
@@ -1483,6 +1496,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   if constexpr (M == 6) { du[4] = quad_bcast<2>(mine[0]); du[5] = quad_bcast<2>(mine[1]); }
 #pragma unroll
   for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
+  RSTAMP(3)
   State Nx;
   if constexpr (!LINEAR) {
     State Fn = dyn_f_k<M, CT, PK>(DK, C, Sn, un);
@@ -1502,6 +1516,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
       cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
       cv = Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
     }
+    RSTAMP(4)
     Nx.X = se3_project(se3_compose(Mx, Fn.X));
     Nx.w = cw + Fn.w;
     Nx.v = cv + Fn.v;
@@ -1517,12 +1532,14 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
     Nx.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
     Nx.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
   }
+  RSTAMP(5)
   if (writer) {
     __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
 #pragma unroll
     for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
     store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
   }
+  RSTAMP(6)
   return Nx;
 }
 
@@ -1549,16 +1566,24 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
     Sn = load_state_b(mkbuf(P.cand + (size_t)13 * P.Bp * i0, 13 * sB), vb, sB);
   }
   const DynK DK = dynk_load(C);
+#ifdef TOLG_STAMPS
+  RStamps ST;
+  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+  ST.t = __builtin_amdgcn_s_memtime();
+#endif
   State Sa = roll_load_state(P, i0, vb, sB), Sb = Sa;
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn RST_ARG);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn RST_ARG);
   }
+#ifdef TOLG_STAMPS
+  if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -195,6 +195,63 @@ TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
   w = v3(c * q.x, c * q.y, c * q.z);
   v = ljacinv_apply(w, cl, X.t);
 }
+// ------------------------------------------------------------------------------------------------
+// Series fast paths for the sequential rollout (K3), where Exp and Log sit on the critical path of a
+// wave that has nothing else to run.  Inside their domains they need no sqrt, no sincos / atan2 and no
+// division; truncation errors are below 1e-17 relative, i.e. they agree with the closed forms above
+// to rounding.  Outside (a rotation of more than 1 rad per step, a deviation of more than ~29 degrees)
+// they fall back to the closed forms; manif's small-angle branches (th2 <= 1e-10) are kept as they are.
+// ------------------------------------------------------------------------------------------------
+// sum_k c[k] y^k, Horner
+template <int N>
+TOLG_DEV double horner(const double (&c)[N], double y) {
+  double r = c[N - 1];
+#pragma unroll
+  for (int k = N - 2; k >= 0; k--) r = fma(r, y, c[k]);
+  return r;
+}
+TOLG_DEV Pose se3_exp_fast(V3 w, V3 v) {
+  const double th2 = dot(w, w);
+  if (!(th2 > TOLG_EPS && th2 < 1.0)) return se3_exp(w, v);
+  // x = th/2, y = x^2:  sin(x)/x, cos(x), and (th - sin th)/th^3 as series in y resp. th2
+  const double S[9] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
+                       -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
+  const double Cc[9] = {1.0, -1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600,
+                        -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+  const double Bc[10] = {1.0 / 6, -1.0 / 120, 1.0 / 5040, -1.0 / 362880, 1.0 / 39916800, -1.0 / 6227020800.0,
+                         1.0 / 1307674368000.0, -1.0 / 355687428096000.0, 1.0 / 121645100408832000.0,
+                         -1.0 / 51090942171709440000.0};
+  const double y = 0.25 * th2;
+  const double so = 0.5 * horner(S, y);  // sin(th/2)/th
+  Pose X;
+  X.q.x = so * w.x; X.q.y = so * w.y; X.q.z = so * w.z; X.q.w = horner(Cc, y);
+  SO3Coef k;
+  k.a = 2.0 * so * so;                    // (1 - cos th)/th^2 = 2 sin^2(th/2)/th^2
+  k.b = horner(Bc, th2);                  // (th - sin th)/th^3
+  k.c1 = k.c2 = k.c3 = 0;
+  X.t = ljac_apply(w, k, v);
+  return X;
+}
+TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
+  const Q4 q = X.q;
+  const double y = q.x * q.x + q.y * q.y + q.z * q.z;  // sin^2 of the half angle
+  if (!(y > TOLG_EPS && y < 0.0625)) { se3_log(X, w, v); return; }
+  // asin(sqrt y)/sqrt y and 1/t^2 - cot(t/2)/(2t) = sum |B_{2k+2}|/(2k+2)! t^2k
+  const double A[14] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144, 0.030381944444444444,
+                        0.022372159090909092, 0.017352764423076924, 0.01396484375, 0.011551800896139705,
+                        0.009761609529194078, 0.008390335809616815, 0.0073125258735988454, 0.006447210311889649,
+                        0.005740037670841924};
+  const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
+                       2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
+                       8.586062056277845e-15};
+  double c = 2.0 * horner(A, y);        // angle / |q_v|
+  const double t2 = c * c * y;          // angle^2
+  double cl = horner(L, t2);
+  if (t2 <= TOLG_EPS) cl = 0.0;         // manif's small-angle V^-1 = I - W/2
+  if (q.w < 0.0) c = -c;                // q and -q are the same rotation: take the w > 0 representative
+  w = v3(c * q.x, c * q.y, c * q.z);
+  v = ljacinv_apply(w, cl, X.t);
+}
 TOLG_DEV Pose se3_compose(Pose A, Pose B) {
   Pose C;
   C.q = qmul(A.q, B.q);
