@@ -272,14 +272,16 @@ TOLG_DEV DynK dynk_load(const CT& C) {
   K.mg = pin_v(C.mass * C.grav);
   return K;
 }
-// dyn_f with the pinned constants: the same expressions in the same order as the diagJ branch above
+// dyn_f with the pinned constants: the same expressions in the same order as the diagJ branch above,
+// in two halves.  The pose half needs the state only, so the rollout runs it while the gains it is
+// about to multiply are still in flight.
+TOLG_DEV Pose dyn_pose_k(const DynK& K, const State& S) {
+  Pose E = se3_exp_fast(K.dt * S.w, K.dt * S.v);
+  return se3_project(se3_compose(S.X, E));
+}
 template <int M, class CT, int PK>
-TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double (&u)[M]) {
-  if (!K.diag) return dyn_f<M, CT, PK>(C, S, u);
-  State F;
+TOLG_DEV void dyn_twist_k(const DynK& K, const CT& C, const State& S, const double (&u)[M], State& F) {
   const double dt = K.dt;
-  Pose E = se3_exp_fast(dt * S.w, dt * S.v);
-  F.X = se3_project(se3_compose(S.X, E));
   V3 y1 = v3(K.ib[0] * S.w.x, K.ib[1] * S.w.y, K.ib[2] * S.w.z);
   V3 y2 = v3(K.jv[0] * S.v.x, K.jv[1] * S.v.y, K.jv[2] * S.v.z);
   V3 top = cross(y1, S.w) + cross(y2, S.v);
@@ -295,6 +297,13 @@ TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double 
   else bot = bot + v3(0, 0, u[3]);
   F.w = S.w + v3(K.bt[0] * top.x, K.bt[1] * top.y, K.bt[2] * top.z);
   F.v = S.v + dt * v3(K.jvi[0] * bot.x, K.jvi[1] * bot.y, K.jvi[2] * bot.z);
+}
+template <int M, class CT, int PK>
+TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double (&u)[M]) {
+  if (!K.diag) return dyn_f<M, CT, PK>(C, S, u);
+  State F;
+  F.X = dyn_pose_k(K, S);
+  dyn_twist_k<M, CT, PK>(K, C, S, u, F);
   return F;
 }
 
@@ -1481,6 +1490,10 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
                   Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
   // du = alpha k + K dx: this lane's two rows, then quad broadcast (identical bits in all four lanes)
+  // the pose half of f(x^, u^) does not depend on u^: it runs here, ahead of the gain product, and gives
+  // the gain loads issued at the top of the step another ~700 cycles to land
+  State Fn;
+  if (!LINEAR && DK.diag) Fn.X = dyn_pose_k(DK, Sn);
   RSTAMP(2)
   double mine[2];
 #pragma unroll
@@ -1499,7 +1512,8 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   RSTAMP(3)
   State Nx;
   if constexpr (!LINEAR) {
-    State Fn = dyn_f_k<M, CT, PK>(DK, C, Sn, un);
+    if (DK.diag) dyn_twist_k<M, CT, PK>(DK, C, Sn, un, Fn);
+    else Fn = dyn_f<M, CT, PK>(C, Sn, un);
     Pose Mx;
     V3 cw, cv;
     if constexpr (ALPHA1) {
