@@ -1503,17 +1503,21 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   const unsigned vr = REC_VR(b);
+  // Lanes for which a block of the column is structurally zero load it from an out-of-range offset: raw
+  // buffer loads return 0 there, which replaces thirty mask multiplications per knot (x * 1.0 was exact).
+  const unsigned OOB = 0x40000000u;
   unsigned oT[3], oM[3];  // fT / fM are odd for every second lane: per-row offsets instead of base + r
 #pragma unroll
-  for (int r = 0; r < 3; r++) { oT[r] = vr + FOFF(fT + r); oM[r] = vr + FOFF(fM + r); }
-  const unsigned vBt = vr + FOFF(fB);  // fB is even (REC_A22, REC_D even): rows r, r+1 are one 16-byte pair
+  for (int r = 0; r < 3; r++) { oT[r] = (mT != 0.0) ? vr + FOFF(fT + r) : OOB; oM[r] = (mM != 0.0) ? vr + FOFF(fM + r) : OOB; }
+  const bool hasB = (j >= 6 && j < 12) || j == 12, isVec = (j == 12 || j == 13);
+  const unsigned vBt = hasB ? vr + FOFF(fB) : OOB;  // fB is even (REC_A22, REC_D even): rows r, r+1 are one 16-byte pair
+  const unsigned vVec = isVec ? vr : OOB;           // fields only the vector columns read (l_x[6:12], l_u)
   const unsigned vG = GK_VG(b, M) + GOFF(0, (j < 13 ? j : 12), M);
   const unsigned vUU = vr + FOFF(REC_LUU + (j < M ? j : 0));
   unsigned vL[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) vL[r] = vr + FOFF(fL[r]);
+  for (int r = 0; r < 6; r++) vL[r] = (mLT != 0.0) ? vr + FOFF(fL[r]) : OOB;
   const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
-  const double mB = ((j >= 6 && j < 12) || j == 12) ? 1.0 : 0.0;
   double Cg[GRAV ? 3 : 1][6];
   if constexpr (GRAV) {
 #pragma unroll
@@ -1530,10 +1534,10 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, REC_F * sB);
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, REC_VR(b), FOFF(REC_LX + 6 + r));
-      V[r] = mLT * t1;
+      double t1 = bld(rR, vL[r], 0), t2 = bld(rR, vVec, FOFF(REC_LX + 6 + r));
+      V[r] = t1;
       double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
-      V[6 + r] = mvec * t2 + p2;
+      V[6 + r] = t2 + p2;
     }
   }
   double gsum = 0;
@@ -1564,9 +1568,9 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 #pragma unroll
     for (int r = 0; r < 6; r++) in.lt[r] = bld(rR, vL[r], 0);
 #pragma unroll
-    for (int r = 0; r < 6; r += 2) bld2(rR, REC_VR(b), FOFF(REC_LX + 6 + r), in.lb[r], in.lb[r + 1]);
+    for (int r = 0; r < 6; r += 2) bld2(rR, vVec, FOFF(REC_LX + 6 + r), in.lb[r], in.lb[r + 1]);
 #pragma unroll
-    for (int a = 0; a < M; a += 2) bld2(rR, REC_VR(b), FOFF(REC_LU + a), in.lu[a], in.lu[a + 1]);
+    for (int a = 0; a < M; a += 2) bld2(rR, vVec, FOFF(REC_LU + a), in.lu[a], in.lu[a + 1]);
     in.luu = bld(rR, vUU, 0);  // lane u < M: the AL addition to l_uu[u][u]
     if constexpr (VARB) {
 #pragma unroll
@@ -1591,17 +1595,17 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     double A[12], Lc[12], lu[M];
     const double luu_i = in.luu;
 #pragma unroll
-    for (int r = 0; r < 3; r++) { A[r] = mT * in.t[r]; A[3 + r] = mM * in.m[r]; }
+    for (int r = 0; r < 3; r++) { A[r] = in.t[r]; A[3 + r] = in.m[r]; }
 #pragma unroll
-    for (int r = 0; r < 6; r++) A[6 + r] = mB * in.bt[r];
+    for (int r = 0; r < 6; r++) A[6 + r] = in.bt[r];
     if constexpr (GRAV) {
 #pragma unroll
       for (int r = 0; r < 6; r++) A[6 + r] += in.g[0] * Cg[0][r] + in.g[1] * Cg[1][r] + in.g[2] * Cg[2][r];
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) { Lc[r] = mLT * in.lt[r]; Lc[6 + r] = mvec * in.lb[r]; }  // + 2 W2: added to Qh below
+    for (int r = 0; r < 6; r++) { Lc[r] = in.lt[r]; Lc[6 + r] = in.lb[r]; }  // + 2 W2: added to Qh below
 #pragma unroll
-    for (int a = 0; a < M; a++) lu[a] = mvec * in.lu[a];  // l_u = 2 R u rides in the vector columns
+    for (int a = 0; a < M; a++) lu[a] = in.lu[a];  // l_u = 2 R u rides in the vector columns (zero elsewhere)
     STAMP(0)
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; adjoint passes through)
     double Z[12];
