@@ -2645,6 +2645,8 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   if (check_problem(prob) || !d_q_ref || !d_xi_ref || !d_workspace || !out || max_batch < 1) return TOLG_E_ARG;
   if (workspace_bytes < tolg_workspace_bytes(prob, max_batch)) return TOLG_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) != 0) return TOLG_E_ARG;
+  // one knot of records must stay below the out-of-range offset K2 uses for structurally-zero loads (1 GiB)
+  if ((size_t)((max_batch + 3) / 4 * 4) * REC_F * 8 >= 0x40000000ull) return TOLG_E_ARG;
   tolg_handle_s* h = new (std::nothrow) tolg_handle_s();
   if (!h) return TOLG_E_ARG;
   h->prob = *prob;
