@@ -1,4 +1,5 @@
-# SQ counter passes over the bench for two rollout workgroup sizes (diagnostic)
+# SQ counter passes for two rollout workgroup sizes (historical diagnostic: needs the TOLG_ROLL_WG switch, removed after the experiment;
+# results: profiles/r01_k3_cu_sharing_pmc.json)
 export TMPDIR=/tmp
 for wg in 64 256; do
   export TOLG_ROLL_WG=$wg
