@@ -722,15 +722,16 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 __global__ void k_reduce(Params P, int it) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
-  // fixed summation order (knot 0, 1, 2, ...) with the loads batched eight at a time
+  // fixed summation order (knot 0, 1, 2, ...); 64 waves cannot hide memory latency, so the loads go out
+  // sixteen knots (32 loads) at a time
   double J = 0, d2 = 0;
   int i = 0;
-  for (; i + 8 <= P.N; i += 8) {
-    double c[8], d[8];
+  for (; i + 16 <= P.N; i += 16) {
+    double c[16], d[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { c[k] = P.SC[(size_t)(i + k) * P.Bp + b]; d[k] = P.SD[(size_t)(i + k) * P.Bp + b]; }
+    for (int k = 0; k < 16; k++) { c[k] = P.SC[(size_t)(i + k) * P.Bp + b]; d[k] = P.SD[(size_t)(i + k) * P.Bp + b]; }
 #pragma unroll
-    for (int k = 0; k < 8; k++) { J += c[k]; d2 += d[k]; }
+    for (int k = 0; k < 16; k++) { J += c[k]; d2 += d[k]; }
   }
   for (; i < P.N; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
   J += P.SC[(size_t)P.N * P.Bp + b];
