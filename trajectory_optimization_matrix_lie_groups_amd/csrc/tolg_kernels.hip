@@ -1908,7 +1908,13 @@ struct RollIn {
 };
 template <int L>
 TOLG_DEV double quad_bcast(double x) {  // value of x in lane L of this lane's quad
-  return __builtin_amdgcn_update_dpp(0.0, x, L | (L << 2) | (L << 4) | (L << 6), 0xf, 0xf, false);
+  // on the two 32-bit halves: only row_newbcast exists as a 64-bit DPP move, and the type-generic builtin
+  // applied to a double has been seen to convert its result numerically (see row_shl6)
+  constexpr int ctrl = L | (L << 2) | (L << 4) | (L << 6);
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 TOLG_DEV State roll_load_state(const Params& P, int i, unsigned vb, unsigned sB) {
   return load_state_b(mkbuf(P.cur + (size_t)13 * P.Bp * i, 13 * sB), vb, sB);
