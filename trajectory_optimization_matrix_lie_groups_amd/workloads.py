@@ -77,6 +77,8 @@ def perturbed_batch(q0, xi0, B, scale_pose, scale_twist, seed=SEED):
 def se3_tracking(B, N=200, R_scale=1e-5, seed=SEED):
     """BASELINE metric / config 3: SE3 exact tracking, N=200, dt=0.05 on path_se3_generate_sine_2."""
     q_ref, xi_ref, dt = load_reference("se3_sine2_n200")
+    if N + 1 > q_ref.shape[0]:
+        raise ValueError("path_se3_generate_sine_2 has %d knots: horizon N must be <= %d" % (q_ref.shape[0], q_ref.shape[0] - 1))
     q_ref, xi_ref = q_ref[: N + 1], xi_ref[: N + 1]
     Q = np.diag([25.0, 25, 25, 10, 10, 10, 1, 1, 1, 1, 1, 1])
     prob = TrackingProblem("se3", inertia(), dt, Q, np.eye(6) * R_scale, 1.5 * Q, q_ref, xi_ref)
