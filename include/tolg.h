@@ -37,7 +37,14 @@ extern "C" {
 enum { TOLG_DYN_SE3 = 0, TOLG_DYN_RIGIDBODY = 1, TOLG_DYN_DRONE = 2, TOLG_DYN_SO3 = 3, TOLG_DYN_PENDULUM3D = 4 };
 enum { TOLG_MODE_MS = 0, TOLG_MODE_SS = 1 };
 enum { TOLG_E_ARG = -1, TOLG_E_WORKSPACE = -2, TOLG_E_LAUNCH = -3, TOLG_E_SINGULAR = -4 };
-enum { TOLG_ST_OK = 0, TOLG_ST_MAXREG = 1, TOLG_ST_NODESCENT = 2, TOLG_ST_NONFINITE = 3 };
+/* TOLG_ST_INTERNAL: a wavefront of the fused rollout gave up waiting for its producer (never expected; it
+ * replaces a GPU hang by a visible status). */
+enum { TOLG_ST_OK = 0, TOLG_ST_MAXREG = 1, TOLG_ST_NODESCENT = 2, TOLG_ST_NONFINITE = 3, TOLG_ST_INTERNAL = 4 };
+/* tolg_options.schedule: how one accept-always MS iteration (line_search = 0, rollout = 'nonlinear') is
+ * issued.  AUTO: the rollout and the re-linearisation of the new trajectory share one launch (k_rollout_lin);
+ * SPLIT: separate rollout and linearisation launches (the only form for every other mode).  Same results
+ * either way up to the summation order inside lin_knot (identical code). */
+enum { TOLG_SCHED_AUTO = 0, TOLG_SCHED_SPLIT = 1 };
 
 /* Problem = one (dynamics, cost) pair shared by the whole batch.
  * Replaces the constructor arguments of SE3Dynamics / RigidBodyDynamics / DroneDynamics
@@ -69,6 +76,8 @@ typedef struct {
   double tol_grad;         /* tol_grad_norm */
   double tol_defect;       /* tol_d_norm (MS) */
   double max_reg;          /* max_reg (1e10) */
+  int32_t schedule;        /* TOLG_SCHED_* (no reference counterpart: launch structure only) */
+  int32_t reserved;
 } tolg_options;
 
 typedef struct tolg_handle_s* tolg_handle_t;

@@ -6,7 +6,8 @@ from ._build import lib_path
 
 DYN_SE3, DYN_RIGIDBODY, DYN_DRONE, DYN_SO3, DYN_PENDULUM3D = 0, 1, 2, 3, 4
 MODE_MS, MODE_SS = 0, 1
-ST_OK, ST_MAXREG, ST_NODESCENT, ST_NONFINITE = 0, 1, 2, 3
+ST_OK, ST_MAXREG, ST_NODESCENT, ST_NONFINITE, ST_INTERNAL = 0, 1, 2, 3, 4
+SCHED_AUTO, SCHED_SPLIT = 0, 1
 _ERR = {-1: "bad argument", -2: "workspace too small", -3: "kernel launch failed", -4: "inertia matrix singular"}
 
 
@@ -19,7 +20,7 @@ class Problem(C.Structure):
 class Options(C.Structure):
     _fields_ = [("mode", C.c_int32), ("max_iter", C.c_int32), ("line_search", C.c_int32),
                 ("rollout_linear", C.c_int32), ("tol_grad", C.c_double), ("tol_defect", C.c_double),
-                ("max_reg", C.c_double)]
+                ("max_reg", C.c_double), ("schedule", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

@@ -64,7 +64,8 @@ struct Params {
   double* cand;
   double* cand_u;
   const double* ref;   // [N+1][13] reference pose (quat, pos) and twist, batch-shared
-  double* REC;         // [N+1][REC_F][Bp] compact knot records written by K1 (fields: REC_*)
+  double* REC;         // [N+1][recF][Bp] compact knot records written by K1 (fields: REC_*)
+  int recF, fLUU;      // fields per record for this model / solve (rec_fields()), field index of REC_LUU (AL only)
   double* SC;          // [N+1][Bp] stage costs
   double* SD;          // [N][Bp]   squared defects
   double* GK;          // [N][m*13][Bp]     K (cols 0..11) | k (col 12), row-major per knot
@@ -119,44 +120,50 @@ TOLG_DEV void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, doubl
   f64x2 v = {x0, x1};
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
-// Knot record: everything K2/K3 need from the linearisation, one field per [Bp]-long row so that K1
-// (thread per trajectory, batch fastest) writes fully coalesced and K2's lanes pick the entries of
-// their own column by address.  3x3 blocks are stored column-major (column c at +3c).
+// Knot record: everything K2 (and the line-search rollouts) need from the linearisation.  3x3 blocks are
+// stored column-major (column c at +3c).  The record holds what every model needs (REC_BASE + m fields),
+// then the fields only some models / solves have: the gravity direction (models with a gravity block),
+// the augmented-Lagrangian l_uu diagonal (AL solves); Params::recF is the size for the solve at hand.
+// What is NOT here: the alpha = 1 rollout factors M_i = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 and
+// c_i = xi_{i+1} - f_xi(x_i,u_i) + d_xi of traopt_controller.py:2713-2716.  With d = Log(x_{i+1}^-1 f_q)
+// they are the identity and zero up to rounding (Exp(Log(X)) = X), so the alpha = 1 step is
+// x^_{i+1} = f(x^_i, u^_i); only the alpha < 1 line-search rollouts build the factors (from REC_D).
 enum {
   REC_RI = 0,    // R(Exp(xi dt))^T                     -> F_x[0:3,0:3] = F_x[3:6,3:6]
   REC_TRI = 9,   // [t_inv]x R^T                        -> F_x[3:6,0:3]
   REC_JR = 18,   // dt Jr(w dt)                         -> F_x[0:3,6:9] = F_x[3:6,9:12]
   REC_QR = 27,   // dt Q(-v dt,-w dt)                   -> F_x[3:6,6:9]
   REC_D = 36,    // defect (12)
-  REC_RTE = 48,  // R^T (0,0,-1) (gravity direction in the body frame), 0 for SE3Dynamics
-  REC_LXX = 51,  // l_xx pose block, symmetric packed (21)
-  REC_LX = 72,   // l_x (12)
-  REC_M = 84,    // rollout left factor M = x_{i+1} Exp(d_q) f_q(x_i,u_i)^-1 (quaternion xyzw, t)
-  REC_C = 91,    // rollout offset c = xi_{i+1} - f_xi(x_i,u_i) + d_xi
-  REC_A22 = 98,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]   (97 is padding: pairs below)
-  REC_LU = 134,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
-  REC_LUU = 140, // diagonal added to l_uu = 2 R by the augmented Lagrangian (m), 0 otherwise
-  REC_F = 146,
+  REC_LXX = 48,  // l_xx pose block, symmetric packed (21; 69 is padding: pairs below)
+  REC_LX = 70,   // l_x (12)
+  REC_A22 = 82,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
+  REC_LU = 118,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
+  REC_BASE = 118,
+  // REC_LU + m: R^T (0,0,-1) (gravity direction in the body frame, 3 + 1 padding), gravity models only
+  // Params::fLUU: diagonal added to l_uu = 2 R by the augmented Lagrangian (m), AL solves only
+  REC_FMAX = REC_BASE + 6 + 4 + 6,
   // Pendulum3dDyanmics only: F_u[6:9,0:3] = J^-1 skew(m rho) R^T dt (state dependent), row-major, in the
   // slot of REC_TRI -- that block of F_x is identically zero without a translation, and an extra
-  // field would leave a never-written hole in every 4.6 KB record group of all the other models
+  // field would leave a never-written hole in every record group of all the other models
   REC_BU = REC_TRI
 };
+__host__ __device__ inline int rec_rte(int m) { return REC_LU + m; }
+__host__ __device__ inline int rec_fields(int m, bool grav, bool al) { return REC_BASE + m + (grav ? 4 : 0) + (al ? m : 0); }
 // Records and gains are interleaved by four trajectories and by field pairs:
 // REC [knot][b / 4][field / 2][b % 4][field % 2], GK [knot][b / 4][column j][row u / 2][b % 4][u % 2].
-// The four trajectories of one K2 wavefront then own one contiguous 4.7 KB run per knot (every 64-byte
+// The four trajectories of one K2 wavefront then own one contiguous run per knot (every 64-byte
 // sector it touches is entirely its own; with a plain [knot][field][Bp] layout K2 fetched every
 // 128-byte line four times), while a thread that owns one trajectory moves two neighbouring fields with
-// one 16-byte access: K1 stores, K2's A22 / l_x / l_u loads and gain stores, K3's gain-row and rollout
-// factor loads.  Runs that are read or written as pairs start on even fields (REC_D, REC_LX, REC_M,
-// REC_A22, REC_LU).  Store-pattern microbenchmark: profiles/r01_store_microbench.txt.
+// one 16-byte access: K1 stores, K2's A22 / l_x / l_u loads and gain stores, K3's gain-row loads.
+// Runs that are read or written as pairs start on even fields (REC_D, REC_LX, REC_A22, REC_LU); recF is even.
+// Store-pattern microbenchmark: profiles/r01_store_microbench.txt.
 #define RIDX(i, f, b) \
-  (((size_t)(i)) * REC_F * (size_t)P.Bp + (((size_t)(b)) >> 2) * (REC_F * 4) + (((size_t)(f)) >> 1) * 8 + (((size_t)(b)) & 3) * 2 + (((size_t)(f)) & 1))
+  (((size_t)(i)) * (size_t)P.recF * (size_t)P.Bp + (((size_t)(b)) >> 2) * ((size_t)P.recF * 4) + (((size_t)(f)) >> 1) * 8 + (((size_t)(b)) & 3) * 2 + (((size_t)(f)) & 1))
 #define GKIDX(i, u, b, j) \
   (((size_t)(i)) * 13 * (size_t)P.m * (size_t)P.Bp + (((size_t)(b)) >> 2) * 13 * (size_t)P.m * 4 +    \
    (((size_t)(j)) * ((size_t)P.m / 2) + (((size_t)(u)) >> 1)) * 8 + (((size_t)(b)) & 3) * 2 + (((size_t)(u)) & 1))
 // byte offsets for the buffer accessors: the lane's base inside one knot, then field / gain-entry offsets
-#define REC_VR(b) ((unsigned)((b) >> 2) * (REC_F * 32u) + (unsigned)((b) & 3) * 16u)
+#define REC_VR(b) ((unsigned)((b) >> 2) * ((unsigned)P.recF * 32u) + (unsigned)((b) & 3) * 16u)
 #define GK_VG(b, M_) ((unsigned)((b) >> 2) * (13u * (M_) * 32u) + (unsigned)((b) & 3) * 16u)
 #define FOFF(f) ((((unsigned)(f)) >> 1) * 64u + (((unsigned)(f)) & 1u) * 8u)
 #define GOFF(u, j, M_) ((((unsigned)(j)) * ((M_) / 2u) + (((unsigned)(u)) >> 1)) * 64u + (((unsigned)(u)) & 1u) * 8u)
@@ -435,33 +442,18 @@ TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: linearisation, one thread per (trajectory, knot)
+// K1: linearisation of one knot (dynamics f, MS defect, F_x blocks, cost gradient / Gauss-Newton Hessian).
+// lin_knot is the body; k_linearize runs it one thread per (trajectory, knot) on a stored trajectory,
+// k_rollout_lin (below) runs it in helper wavefronts on the states the rollout has just produced.
+// ms: 1 multiple shooting, 0 single shooting, 2 probe (tolg_eval_knot: f(x,u) goes to knot i of P.cand,
+// the tracking error to REC_D, nothing is read from knot i+1).  next_state() returns the state of knot
+// i + 1 (called once, late, and only for ms == 1 on a non-terminal knot).
 // ------------------------------------------------------------------------------------------------
-template <int M>
-__global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
-                                                    const double* __restrict__ src_u, double* __restrict__ dst,
-                                                    double* __restrict__ dst_u, int ms, int i0, int ni) {
-  // ms: 1 multiple shooting, 0 single shooting, 2 probe (tolg_eval_knot: f(x,u) goes to REC_M/REC_C,
-  // the tracking error to REC_D, nothing is read from knot i+1); knots [i0, i0 + ni)
-  const DConsts& C = *(const DConsts*)P.c;
-  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)ni * P.Bp) return;
-  const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
-  if (!P.active[b]) return;
+template <int M, class CT, class NextFn>
+TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const State& S, const double (&u)[M],
+                       NextFn next_state) {
   const bool term = (i == P.N);
   const double dt = C.dt;
-  State S = load_state(P, src, i, b);
-  if (dst) store_state(P, dst, i, b, S);
-  double u[M];
-#pragma unroll
-  for (int a = 0; a < M; a++) u[a] = 0;
-  if (!term) {
-#pragma unroll
-    for (int a = 0; a < M; a++) {
-      u[a] = src_u[UIDX(a, i, b)];
-      if (dst_u) dst_u[UIDX(a, i, b)] = u[a];
-    }
-  }
   // ---------------- cost: e = Log(X Xref^-1), J_e = Jr^-1(e) Ad(Xref)  (traopt_cost.py:659-839)
   {
     const double* r = P.ref + 13 * (size_t)i;
@@ -549,7 +541,13 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
         }
       }
       rec_run<REC_LU, M>(P, i, b, lu);
-      rec_run<REC_LUU, M>(P, i, b, luu);
+      if (P.al_lb) {  // the field exists in AL solves only (Params::fLUU, even)
+#pragma unroll
+        for (int k = 0; k < M; k += 2) {
+          f64x2 w = {luu[k], luu[k + 1]};
+          *reinterpret_cast<f64x2*>(&P.REC[RIDX(i, P.fLUU + k, b)]) = w;
+        }
+      }
     }
     P.SC[(size_t)i * P.Bp + b] = l;
     double WJ[36];
@@ -658,8 +656,8 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
       }
     rec_run<REC_A22, 36>(P, i, b, a22);
   }
-  {
-    V3 rte = (C.grav != 0.0) ? qrot_inv(S.X.q, v3(0, 0, -1.0)) : v3(0, 0, 0);
+  if (C.grav != 0.0) {  // gravity models only (the field does not exist otherwise)
+    V3 rte = qrot_inv(S.X.q, v3(0, 0, -1.0));
     if (C.kind == TOLG_DYN_PENDULUM3D) {
       // Pendulum3dDyanmics.f_x / f_u (traopt_dynamics.py:574-609).  L1 + L2 = skew(m rho) skew(w) with
       // w = R^T (g (0,0,-1) + u): the lower-left block stays linear in one body-frame vector, which takes
@@ -678,43 +676,57 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
       for (int k = 0; k < 9; k++) P.REC[RIDX(i, REC_BU + k, b)] = dt * Bu[k];
     }
     const double rt[3] = {rte.x, rte.y, rte.z};
-    rec_run<REC_RTE, 3>(P, i, b, rt);
+    rec_run<REC_LU + M, 3>(P, i, b, rt);
   }
   // ---------------- defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}]  (traopt_controller.py:2882-2888)
-  // and the rollout factors of traopt_controller.py:2713-2716 for alpha = 1
   double d[12];
-  Pose Mx;
-  V3 cw, cv;
   if (ms == 2) {  // probe: export f(x, u) itself
     State F = dyn_f<M>(C, S, u);
-    const double mc[13] = {F.X.q.x, F.X.q.y, F.X.q.z, F.X.q.w, F.X.t.x, F.X.t.y, F.X.t.z, F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
-    rec_run<REC_M, 13>(P, i, b, mc);
+    store_state(P, P.cand, i, b, F);
     return;
   }
   if (ms) {
     State F = dyn_f<M>(C, S, u);
-    State Sn = load_state(P, src, i + 1, b);
+    State Sn = next_state();
     V3 dw, dv;
     se3_log(se3_compose(se3_inverse(Sn.X), F.X), dw, dv);
     d[0] = dw.x; d[1] = dw.y; d[2] = dw.z; d[3] = dv.x; d[4] = dv.y; d[5] = dv.z;
     V3 dxw = F.w - Sn.w, dxv = F.v - Sn.v;
     d[6] = dxw.x; d[7] = dxw.y; d[8] = dxw.z; d[9] = dxv.x; d[10] = dxv.y; d[11] = dxv.z;
-    Mx = se3_compose(se3_compose(Sn.X, se3_exp(dw, dv)), se3_inverse(F.X));
-    cw = Sn.w - F.w + dxw;
-    cv = Sn.v - F.v + dxv;
   } else {
 #pragma unroll
     for (int a = 0; a < 12; a++) d[a] = 0;
-    Mx.q.x = 0; Mx.q.y = 0; Mx.q.z = 0; Mx.q.w = 1; Mx.t = v3(0, 0, 0);
-    cw = v3(0, 0, 0); cv = v3(0, 0, 0);
   }
   double d2 = 0;
 #pragma unroll
   for (int a = 0; a < 12; a++) d2 += d[a] * d[a];
   rec_run<REC_D, 12>(P, i, b, d);
   P.SD[(size_t)i * P.Bp + b] = d2;
-  const double mc[13] = {Mx.q.x, Mx.q.y, Mx.q.z, Mx.q.w, Mx.t.x, Mx.t.y, Mx.t.z, cw.x, cw.y, cw.z, cv.x, cv.y, cv.z};
-  rec_run<REC_M, 13>(P, i, b, mc);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
+                                                    const double* __restrict__ src_u, double* __restrict__ dst,
+                                                    double* __restrict__ dst_u, int ms, int i0, int ni) {
+  // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read
+  const DConsts& C = *(const DConsts*)P.c;
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)ni * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
+  if (!P.active[b]) return;
+  State S = load_state(P, src, i, b);
+  if (dst) store_state(P, dst, i, b, S);
+  double u[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) u[a] = 0;
+  if (i < P.N) {
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      u[a] = src_u[UIDX(a, i, b)];
+      if (dst_u) dst_u[UIDX(a, i, b)] = u[a];
+    }
+  }
+  lin_knot<M>(P, C, i, b, ms, S, u, [&]() { return load_state(P, src, i + 1, b); });
 }
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
@@ -1514,11 +1526,12 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   const unsigned vBt = hasB ? vr + FOFF(fB) : OOB;  // fB is even (REC_A22, REC_D even): rows r, r+1 are one 16-byte pair
   const unsigned vVec = isVec ? vr : OOB;           // fields only the vector columns read (l_x[6:12], l_u)
   const unsigned vG = GK_VG(b, M) + GOFF(0, (j < 13 ? j : 12), M);
-  const unsigned vUU = vr + FOFF(REC_LUU + (j < M ? j : 0));
+  // the l_uu field exists in AL solves only: without AL every lane reads it out of range (= 0), branch-free
+  const unsigned vUU = (P.al_lb != nullptr) ? vr + FOFF(P.fLUU + (j < M ? j : 0)) : OOB;
   unsigned vL[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) vL[r] = (mLT != 0.0) ? vr + FOFF(fL[r]) : OOB;
-  const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  const size_t recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   double Cg[GRAV ? 3 : 1][6];
   if constexpr (GRAV) {
 #pragma unroll
@@ -1532,7 +1545,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
   double V[12];
   {
-    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, REC_F * sB);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, (unsigned)P.recF * sB);
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       double t1 = bld(rR, vL[r], 0), t2 = bld(rR, vVec, FOFF(REC_LX + 6 + r));
@@ -1554,7 +1567,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   // data right behind the request and undo the prefetch.
   struct BwdIn { double t[3], m[3], bt[6], g[GRAV ? 3 : 1], lt[6], lb[6], lu[M], luu, bu[VARB ? 9 : 1]; };
   auto load_knot = [&](int i, BwdIn& in) {
-    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       in.t[r] = bld(rR, oT[r], 0);
@@ -1564,7 +1577,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 6; r += 2) bld2(rR, vBt, FOFF(r), in.bt[r], in.bt[r + 1]);
     if constexpr (GRAV) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), FOFF(REC_RTE + a));
+      for (int a = 0; a < 3; a++) in.g[a] = bld(rR, REC_VR(b), FOFF(REC_LU + M + a));
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) in.lt[r] = bld(rR, vL[r], 0);
@@ -1846,9 +1859,10 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
 // :2030-2082 SS).  The reference's MS step
 //     q^_{i+1} = q_{i+1} Exp(alpha d_q) f_q(x_i,u_i)^-1 f_q(x^_i,u^_i),
 //     xi^_{i+1} = xi_{i+1} + f_xi(x^_i,u^_i) - f_xi(x_i,u_i) + alpha d_xi
-// is M_i o f_q(x^_i,u^_i), c_i + f_xi(x^_i,u^_i) with (M_i, c_i) independent of the new trajectory:
-// K1 precomputes them in parallel for alpha = 1 (REC_M, REC_C; identity / zero for SS), so the
-// sequential chain holds one Log, one Exp and the K dx product per knot.
+// is M_i o f_q(x^_i,u^_i), c_i + f_xi(x^_i,u^_i) with (M_i, c_i) independent of the new trajectory.
+// For alpha = 1 (and for single shooting) M_i = x_{i+1} Exp(Log(x_{i+1}^-1 f_q)) f_q^-1 is the identity
+// and c_i is zero up to rounding, so the sequential chain holds one Log, one Exp and the K dx product
+// per knot; the alpha < 1 line-search steps build the factors from the stored defect.
 // ------------------------------------------------------------------------------------------------
 template <int M>
 TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const double (&e)[12],
@@ -1872,7 +1886,8 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
     lin[r] = t;
     lin[3 + r] = m;
   }
-  double rte[3] = {P.REC[RIDX(i, REC_RTE, b)], P.REC[RIDX(i, REC_RTE + 1, b)], P.REC[RIDX(i, REC_RTE + 2, b)]};
+  double rte[3] = {0, 0, 0};  // the field exists for gravity models only
+  if (C.grav != 0.0) { rte[0] = P.REC[RIDX(i, REC_LU + M, b)]; rte[1] = P.REC[RIDX(i, REC_LU + M + 1, b)]; rte[2] = P.REC[RIDX(i, REC_LU + M + 2, b)]; }
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     double sacc = e[6 + r];
@@ -1903,8 +1918,6 @@ template <int M>
 struct RollIn {
   double G[2][13];   // gain rows 2q and 2q + 1 of [K | k] (one 16-byte pair per column)
   double u[M];
-  Pose Mx;           // REC_M
-  V3 cw, cv;         // REC_C
 };
 template <int L>
 TOLG_DEV double quad_bcast(double x) {  // value of x in lane L of this lane's quad
@@ -1921,8 +1934,7 @@ TOLG_DEV State roll_load_state(const Params& P, int i, unsigned vb, unsigned sB)
 }
 template <int M, bool ALPHA1>
 TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsigned sB, RollIn<M>& R) {
-  const size_t recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
-  __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+  const size_t uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
   __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
   const int qp = (2 * q < M) ? q : M / 2 - 1;  // lanes past the last row pair re-read it (their product is unused)
   const unsigned vg = GK_VG(b, M) + GOFF(2 * qp, 0, M);
@@ -1930,17 +1942,6 @@ TOLG_DEV void roll_load(const Params& P, int i, int b, int q, unsigned vb, unsig
   for (int k = 0; k < 13; k++) bld2(rG, vg, GOFF(0, k, M), R.G[0][k], R.G[1][k]);
 #pragma unroll
   for (int a = 0; a < M; a++) R.u[a] = bld(rU, vb, a * sB);
-  if constexpr (ALPHA1) {
-    // REC_M (7) and REC_C (6) are 13 consecutive fields from an even one: seven 16-byte loads
-    static_assert(REC_M % 2 == 0 && REC_C == REC_M + 7, "rollout factors must start on a field pair");
-    double f[14];
-#pragma unroll
-    for (int k = 0; k < 14; k += 2) bld2(rR, REC_VR(b), FOFF(REC_M + k), f[k], f[k + 1]);
-    R.Mx.q.x = f[0]; R.Mx.q.y = f[1]; R.Mx.q.z = f[2]; R.Mx.q.w = f[3];
-    R.Mx.t = v3(f[4], f[5], f[6]);
-    R.cw = v3(f[7], f[8], f[9]);
-    R.cv = v3(f[10], f[11], f[12]);
-  }
 }
 
 #ifdef TOLG_STAMPS
@@ -1953,10 +1954,12 @@ struct RStamps { unsigned long long acc[8], t; };
 #define RST_PARAM
 #define RST_ARG
 #endif
-template <int M, bool LINEAR, bool ALPHA1, int PK, class CT>
+// STORE: the writer lane stores u^_i and x^_{i+1} to the candidate arrays; otherwise the caller takes them
+// (un_out and the return value) -- the fused rollout hands them to its linearisation wavefronts through LDS.
+template <int M, bool LINEAR, bool ALPHA1, int PK, bool STORE, class CT>
 TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
-                         unsigned sB, double alpha, const State& So, const State& Sn RST_PARAM) {
-  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp;
+                         unsigned sB, double alpha, const State& So, const State& Sn, double (&un_out)[M] RST_PARAM) {
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp;
   RSTAMP(0)
   RollIn<M> R;
   roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R);  // in flight while Log runs
@@ -1992,28 +1995,29 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   if constexpr (!LINEAR) {
     if (DK.diag) dyn_twist_k<M, CT, PK>(DK, C, Sn, un, Fn);
     else Fn = dyn_f<M, CT, PK>(C, Sn, un);
-    Pose Mx;
-    V3 cw, cv;
     if constexpr (ALPHA1) {
-      Mx = R.Mx; cw = R.cw; cv = R.cv;
+      // alpha = 1 (and single shooting): the factors of :2713-2716 are the identity and zero up to rounding
+      // (see the note at the record layout), the step is x^_{i+1} = f(x^_i, u^_i)
+      RSTAMP(4)
+      Nx = Fn;
     } else {
-      // line-search step: rebuild the factors for this alpha from the stored defect
-      __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+      // line-search step: build the factors for this alpha from the stored defect
+      __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
       double d[12];
 #pragma unroll
       for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
       State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f_k<M, CT, PK>(DK, C, So, R.u);
-      Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
-                       se3_inverse(Fo.X));
-      cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
-      cv = Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
+      Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
+                            se3_inverse(Fo.X));
+      V3 cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
+      V3 cv = Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
+      RSTAMP(4)
+      Nx.X = se3_project(se3_compose(Mx, Fn.X));
+      Nx.w = cw + Fn.w;
+      Nx.v = cv + Fn.v;
     }
-    RSTAMP(4)
-    Nx.X = se3_project(se3_compose(Mx, Fn.X));
-    Nx.w = cw + Fn.w;
-    Nx.v = cv + Fn.v;
   } else {
-    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
     double lin[12], d[12];
     fx_apply<M>(P, *P.c, i, b, e, du, lin);
 #pragma unroll
@@ -2025,12 +2029,16 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
     Nx.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
   }
   RSTAMP(5)
-  if (writer) {
-    __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
+  if constexpr (STORE) {
+    if (writer) {
+      __amdgpu_buffer_rsrc_t rCU = mkbuf(P.cand_u + uStride * i, M * sB);
 #pragma unroll
-    for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
-    store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+      for (int a = 0; a < M; a++) bst(rCU, vb, a * sB, un[a]);
+      store_state_b(mkbuf(P.cand + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+    }
   }
+#pragma unroll
+  for (int a = 0; a < M; a++) un_out[a] = un[a];
   RSTAMP(6)
   return Nx;
 }
@@ -2064,18 +2072,185 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   ST.t = __builtin_amdgcn_s_memtime();
 #endif
   State Sa = roll_load_state(P, i0, vb, sB), Sb = Sa;
+  double un_[M];
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn RST_ARG);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un_ RST_ARG);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn RST_ARG);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un_ RST_ARG);
   }
 #ifdef TOLG_STAMPS
   if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 + K1 fused: the accept-always MS iteration (line_search=False, rollout='nonlinear': the setting of
+// every benchmark_*.py) rolls out and re-linearises in ONE launch.  A workgroup owns 16 trajectories:
+// wavefront 0 is the sequential rollout above (four lanes per trajectory), wavefronts 1..NH are
+// linearisation helpers.  The rollout is a dependent chain on one of the CU's four SIMDs and leaves the
+// other three idle; the linearisation of knot i needs only (x^_i, u^_i, x^_{i+1}), i.e. it can start one
+// step behind the rollout.  Wave 0 therefore publishes every new state / control into an LDS ring instead
+// of storing it to HBM, and the helpers -- 64 lanes = 4 consecutive knots x 16 trajectories per pass, each
+// helper taking every NH-th group of four knots -- run lin_knot on them, write the knot records and commit
+// the new trajectory to P.cur in place.  That is safe: knot i of P.cur / P.cur_u is overwritten only after
+// step i of the rollout has completed, which consumed its (prefetched) old value; nothing else reads it.
+// No candidate trajectory is written or re-read (3 x 125 MB per iteration at 4096 x 200), and the separate
+// K1 launch disappears from the critical path (one helper pass, ~7 us, remains as a tail).
+//
+// Synchronisation is LDS only (one workgroup = one CU): LDS operations of a wave execute in order, so
+// "data writes, then counter write" needs no fence, and the s_barrier-free polling keeps wave 0's record /
+// gain prefetches in flight.  sync[0] = number of rollout steps completed (states 0..sync[0] and controls
+// 0..sync[0]-1 are in the ring); sync[1+h] = groups helper h has finished.  Wave 0 never waits for a helper
+// except to reuse a ring slot (the helpers are ~3x faster than the rollout, so it does not happen); a
+// helper waits only for wave 0: no cyclic wait.  Every poll loop is bounded: a stuck counter ends the
+// kernel with TOLG_ST_INTERNAL instead of hanging the GPU.
+// ------------------------------------------------------------------------------------------------
+enum { RL_RING = 24, RL_PAIRS = 10, RL_POLLS = 1 << 21 };  // ring slots (knots); 16-byte field pairs per knot: 7 state + 3 control
+TOLG_DEV bool rl_wait_ge(volatile int* p, int v) {
+  for (int n = 0; n < RL_POLLS; n++) {
+    if (*p >= v) return true;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+// ring slot layout: [pair][trajectory][2] doubles, state fields 0..12 (+ padding) in pairs 0..6, controls in 7..9
+TOLG_DEV void rl_put_state(double* slot, int tt, const State& S) {
+  f64x2* p = reinterpret_cast<f64x2*>(slot) + tt;
+  p[0 * 16] = f64x2{S.X.q.x, S.X.q.y}; p[1 * 16] = f64x2{S.X.q.z, S.X.q.w}; p[2 * 16] = f64x2{S.X.t.x, S.X.t.y};
+  p[3 * 16] = f64x2{S.X.t.z, S.w.x};   p[4 * 16] = f64x2{S.w.y, S.w.z};     p[5 * 16] = f64x2{S.v.x, S.v.y};
+  p[6 * 16] = f64x2{S.v.z, 0.0};
+}
+TOLG_DEV State rl_get_state(const double* slot, int tt) {
+  const f64x2* p = reinterpret_cast<const f64x2*>(slot) + tt;
+  const f64x2 a = p[0 * 16], b = p[1 * 16], c = p[2 * 16], d = p[3 * 16], e = p[4 * 16], f = p[5 * 16], g = p[6 * 16];
+  State S;
+  S.X.q.x = a.x; S.X.q.y = a.y; S.X.q.z = b.x; S.X.q.w = b.y;
+  S.X.t = v3(c.x, c.y, d.x);
+  S.w = v3(d.y, e.x, e.y);
+  S.v = v3(f.x, f.y, g.x);
+  return S;
+}
+template <int M, int NH>
+__global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
+  const DConsts& C = *(const DConsts*)P.c;
+  __shared__ double ring[RL_RING][RL_PAIRS * 16 * 2];
+  __shared__ int sync[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b0 = blockIdx.x * 16, N = P.N;
+  {
+    // is any of the workgroup's trajectories still being solved?  (same answer in every wave: all leave or none)
+    int bb = b0 + (lane & 15);
+    if (bb >= P.Bp) bb = P.Bp - 1;
+    if (!__any(P.active[bb] != 0)) return;
+  }
+  if (threadIdx.x < 4) sync[threadIdx.x] = (threadIdx.x == 0) ? -1 : 0;
+  __syncthreads();
+  volatile int* vs = sync;
+  const unsigned sB = (unsigned)P.Bp * 8u;
+  if (wave == 0) {
+    // ---------------- the rollout (k_rollout<M, false, true, 0>, results to the ring)
+    int b = b0 + (lane >> 2);
+    const int q = lane & 3, tt = lane >> 2;
+    if (b >= P.Bp) b = P.Bp - 1;  // quads past the batch replay the last trajectory; the helpers ignore their slots
+    const bool writer = q == 0;
+    const unsigned vb = (unsigned)b * 8u;
+    State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+    if (writer) rl_put_state(ring[0], tt, Sn);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) vs[0] = 0;
+    const DynK DK = dynk_load(C);
+    State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+    double un[M];
+    bool ok = true;
+#ifdef TOLG_STAMPS
+    RStamps ST;
+    for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+    ST.t = __builtin_amdgcn_s_memtime();
+#endif
+    auto finish_step = [&](int i) {  // publish u^_i, x^_{i+1}
+      if (writer) {
+        f64x2* pu = reinterpret_cast<f64x2*>(ring[i % RL_RING]) + 7 * 16 + tt;
+#pragma unroll
+        for (int a = 0; a < M; a += 2) pu[(a / 2) * 16] = f64x2{un[a], un[a + 1]};
+        rl_put_state(ring[(i + 1) % RL_RING], tt, Sn);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) vs[0] = i + 1;
+    };
+    // Ring back-pressure, checked once per eight steps for the eight slots ahead (a poll is an LDS round trip
+    // on the critical chain): steps i .. i+7 overwrite the slots of knots up to `old` = i + 8 - RL_RING, which
+    // is safe once every group of four knots up to the one holding `old` has been linearised (a group also
+    // reads the first state of the next group).  Helper h owns groups h, h + NH, ...: it must have finished
+    // (old/4 - h) / NH + 1 of them.
+    auto slot_free = [&](int i) -> bool {
+      if ((i & 7) != 0 || i + 8 < RL_RING) return true;
+      const int go = (i + 8 - RL_RING) / 4;
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+        if (go >= h && !rl_wait_ge(vs + 1 + h, (go - h) / NH + 1)) return false;
+      return true;
+    };
+    for (int i = 0; i < N; i += 2) {
+      if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ok = slot_free(i))) break;
+      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i, b, q, writer, vb, sB, 1.0, Sa, Sn, un RST_ARG);
+      finish_step(i);
+      RSTAMP(7)
+      if (i + 1 >= N) break;
+      if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ok = slot_free(i + 1))) break;
+      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i + 1, b, q, writer, vb, sB, 1.0, Sb, Sn, un RST_ARG);
+      finish_step(i + 1);
+      RSTAMP(7)
+    }
+#ifdef TOLG_STAMPS
+    if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
+#endif
+    if (!ok && writer && b0 + tt < P.Bp) P.status[b0 + tt] = TOLG_ST_INTERNAL;
+    return;
+  }
+  // ---------------- linearisation helpers: pass g covers knots 4g .. 4g+3 (lane / 16) of the 16 trajectories (lane % 16)
+  const int h = wave - 1, kk = lane >> 4, tt = lane & 15, b = b0 + tt;
+  const bool mine = b < P.Bp && P.active[b < P.Bp ? b : 0] != 0;
+  const int ngroups = (N + 1 + 3) / 4;
+  int done = 0;
+  for (int g = h; g < ngroups; g += NH) {
+    const int need = (4 * g + 4 < N) ? 4 * g + 4 : N;  // the last state this pass reads
+    if (!rl_wait_ge(vs, need)) {
+      if (mine && kk == 0) P.status[b] = TOLG_ST_INTERNAL;
+      return;
+    }
+    asm volatile("" ::: "memory");
+    const int i = 4 * g + kk;
+    if (mine && i <= N) {
+      const double* slot = ring[i % RL_RING];
+      const State S = rl_get_state(slot, tt);
+      double u[M];
+#pragma unroll
+      for (int a = 0; a < M; a++) u[a] = 0;
+      if (i < N) {
+        const f64x2* pu = reinterpret_cast<const f64x2*>(slot) + 7 * 16 + tt;
+#pragma unroll
+        for (int a = 0; a < M; a += 2) { const f64x2 w = pu[(a / 2) * 16]; u[a] = w.x; u[a + 1] = w.y; }
+#pragma unroll
+        for (int a = 0; a < M; a++) P.cur_u[UIDX(a, i, b)] = u[a];
+      }
+      if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
+      lin_knot<M>(P, C, i, b, 1, S, u, [&]() { return rl_get_state(ring[(i + 1) % RL_RING], tt); });
+    }
+    done++;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every ring read of this pass has returned
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) vs[1 + h] = done;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2138,7 +2313,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai);
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, uStride = (size_t)M * P.Bp,
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp,
                gStride = (size_t)13 * M * P.Bp;
   double* sx = P.slot_x + (size_t)slot * stStride * (N + 1);
   double* su = P.slot_u + (size_t)slot * uStride * N;
@@ -2146,7 +2321,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
   store_state_b(mkbuf(sx, 13 * sB), vb, sB, Sn);
   double J = 0, d2 = 0;
   for (int i = 0; i < N; i++) {
-    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB), rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
     __amdgpu_buffer_rsrc_t rU = mkbuf(P.cur_u + uStride * i, M * sB);
     State So = load_state_b(mkbuf(P.cur + stStride * i, 13 * sB), vb, sB);
     V3 ew, ev;
@@ -2227,11 +2402,11 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   if (b >= P.Bp || !P.active[b]) return;
   const int N = P.N;
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)REC_F * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, gStride = (size_t)13 * M * P.Bp;
   State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
   double c1 = 0, c2 = 0;
   for (int i = 0; i <= N; i++) {
-    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, REC_F * sB);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
     State So = load_state_b(mkbuf(P.cur + stStride * i, 13 * sB), vb, sB);
     V3 ew, ev;
     se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
@@ -2263,7 +2438,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
       c1 += bld(rR, REC_VR(b), FOFF(REC_LU + a)) * du[a];
 #pragma unroll
       for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
-      c2 += du[a] * bld(rR, REC_VR(b), FOFF(REC_LUU + a)) * du[a];
+      if (P.al_lb) c2 += du[a] * bld(rR, REC_VR(b), FOFF(P.fLUU + a)) * du[a];
     }
     double lin[12], d[12];
     fx_apply<M>(P, C, i, b, e, du, lin);
@@ -2423,15 +2598,15 @@ __global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double
   if (luu)
     for (int a = 0; a < m; a++)
       for (int k = 0; k < m; k++)
-        luu[((size_t)b * m + a) * m + k] = 2.0 * C.R[a * m + k] + (a == k ? P.REC[RIDX(i, REC_LUU + a, b)] : 0.0);
-  if (f_q) {
-    Pose X;
-    X.q.x = P.REC[RIDX(i, REC_M + 0, b)]; X.q.y = P.REC[RIDX(i, REC_M + 1, b)];
-    X.q.z = P.REC[RIDX(i, REC_M + 2, b)]; X.q.w = P.REC[RIDX(i, REC_M + 3, b)];
-    X.t = v3(P.REC[RIDX(i, REC_M + 4, b)], P.REC[RIDX(i, REC_M + 5, b)], P.REC[RIDX(i, REC_M + 6, b)]);
-    pose_to_m16(X, f_q + 16 * (size_t)b);
+        luu[((size_t)b * m + a) * m + k] = 2.0 * C.R[a * m + k] + ((a == k && P.al_lb) ? P.REC[RIDX(i, P.fLUU + a, b)] : 0.0);
+  if (f_q || f_xi) {  // f(x, u) was left in knot i of the candidate array by the probe-mode linearisation
+    State F = load_state(P, P.cand, i, b);
+    if (f_q) pose_to_m16(F.X, f_q + 16 * (size_t)b);
+    if (f_xi) {
+      double* x = f_xi + (size_t)b * 6;
+      x[0] = F.w.x; x[1] = F.w.y; x[2] = F.w.z; x[3] = F.v.x; x[4] = F.v.y; x[5] = F.v.z;
+    }
   }
-  if (f_xi) for (int a = 0; a < 6; a++) f_xi[(size_t)b * 6 + a] = P.REC[RIDX(i, REC_C + a, b)];
   if (Fu) {
     double* F = Fu + (size_t)b * 12 * m;
     for (int k = 0; k < 12 * m; k++) F[k] = 0;
@@ -2452,7 +2627,7 @@ __global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double
         F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
       }
     double rte[3];
-    for (int a = 0; a < 3; a++) rte[a] = P.REC[RIDX(i, REC_RTE + a, b)];
+    for (int a = 0; a < 3; a++) rte[a] = (C.grav != 0.0) ? P.REC[RIDX(i, rec_rte(P.m) + a, b)] : 0.0;
     for (int r = 0; r < 6; r++)
       for (int c = 0; c < 6; c++) {
         double lsum = 0;
@@ -2488,7 +2663,7 @@ __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restri
         F[12 * (r + 3) + c + 6] = P.REC[RIDX(i, REC_QR + 3 * c + r, b)];
       }
     double rte[3];
-    for (int a = 0; a < 3; a++) rte[a] = P.REC[RIDX(i, REC_RTE + a, b)];
+    for (int a = 0; a < 3; a++) rte[a] = (C.grav != 0.0) ? P.REC[RIDX(i, rec_rte(P.m) + a, b)] : 0.0;
     for (int r = 0; r < 6; r++)
       for (int c = 0; c < 6; c++) {
         double l = 0;
@@ -2536,9 +2711,6 @@ struct tolg_handle_s {
   int run_it;         // iterations issued so far
   bool running;
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
-  hipStream_t st2;        // library-owned streams for the rollout / re-linearisation overlap:
-  hipStream_t st_roll;    // st2 runs K1, st_roll (null: the caller's stream) the segmented K3
-  hipEvent_t seg_ev[34];  // up to 32 segments + 2
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -2587,7 +2759,7 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   double* cur_u = c.take<double>(m * N * B);
   double* cand = c.take<double>(13 * (N + 1) * B);
   double* cand_u = c.take<double>(m * N * B);
-  double* REC = c.take<double>((N + 1) * (size_t)REC_F * B);
+  double* REC = c.take<double>((N + 1) * (size_t)REC_FMAX * B);
   double* SC = c.take<double>((N + 1) * B);
   double* SD = c.take<double>(N * B);
   double* GK = c.take<double>(N * m * B * 13);
@@ -2653,7 +2825,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   if (workspace_bytes < tolg_workspace_bytes(prob, max_batch)) return TOLG_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) != 0) return TOLG_E_ARG;
   // one knot of records must stay below the out-of-range offset K2 uses for structurally-zero loads (1 GiB)
-  if ((size_t)((max_batch + 3) / 4 * 4) * REC_F * 8 >= 0x40000000ull) return TOLG_E_ARG;
+  if ((size_t)((max_batch + 3) / 4 * 4) * REC_FMAX * 8 >= 0x40000000ull) return TOLG_E_ARG;
   tolg_handle_s* h = new (std::nothrow) tolg_handle_s();
   if (!h) return TOLG_E_ARG;
   h->prob = *prob;
@@ -2666,38 +2838,6 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->running = false;
   h->run_it = 0;
   h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
-  h->st2 = h->st_roll = nullptr;
-  // Rollout / re-linearisation overlap is OFF by default.  Measured on MI355X at 4096x200 (batch-
-  // iterations/s): no overlap 655; K1 segments on a second stream behind the segmented K3 (=1) 607;
-  // the same with disjoint compute-unit masks, K3 on a quarter of the CUs (=2) 448.  Both kernels
-  // stream from HBM through the per-CU address/L1 path (one CU sustains ~10 B/cycle of misses), so K3
-  // needs all 256 CUs to itself: sharing them with K1 or packing K3's waves onto fewer CUs both lose.
-  // TOLG_OVERLAP=1|2 keeps the two variants for A/B runs; TOLG_ROLL_CUS sets the K3 share for =2.
-  {
-    const char* ov = getenv("TOLG_OVERLAP");
-    const int mode = ov ? atoi(ov) : 0;
-    int dev = 0, ncu = 0;
-    if (mode >= 1 && hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu >= 8) {
-      if (mode == 1) {
-        if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) h->st2 = nullptr;
-      } else {
-        const char* rc_env = getenv("TOLG_ROLL_CUS");
-        int nroll = rc_env ? atoi(rc_env) : ncu / 4;
-        if (nroll < 1 || nroll >= ncu) nroll = ncu / 4;
-        const int words = (ncu + 31) / 32;
-        std::vector<uint32_t> m_roll(words, 0u), m_lin(words, 0u);
-        for (int cu = 0; cu < ncu; cu++) (cu < nroll ? m_roll : m_lin)[cu / 32] |= 1u << (cu % 32);
-        if (hipExtStreamCreateWithCUMask(&h->st_roll, (uint32_t)words, m_roll.data()) != hipSuccess) h->st_roll = nullptr;
-        if (!h->st_roll || hipExtStreamCreateWithCUMask(&h->st2, (uint32_t)words, m_lin.data()) != hipSuccess) {
-          if (h->st_roll) (void)hipStreamDestroy(h->st_roll);
-          h->st_roll = h->st2 = nullptr;
-        }
-        (void)hipGetLastError();
-      }
-    }
-  }
-  for (auto& e : h->seg_ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
   c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
@@ -2773,9 +2913,6 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
 extern "C" void tolg_destroy(tolg_handle_t h) {
   if (!h) return;
   for (auto e : h->ev) (void)hipEventDestroy(e);
-  for (auto e : h->seg_ev) (void)hipEventDestroy(e);
-  if (h->st2) (void)hipStreamDestroy(h->st2);
-  if (h->st_roll) (void)hipStreamDestroy(h->st_roll);
   delete h;
 }
 
@@ -2829,6 +2966,9 @@ static Params params_for(tolg_handle_s* h, int B) {
   P.J_hist = P.grad_hist = P.defect_hist = P.alpha_hist = P.mu_hist = nullptr;
   P.max_iter = 0; P.tol_grad = 0; P.tol_defect = 0; P.max_reg = 1e10;
   P.al_lb = h->al_lb; P.al_ub = h->al_ub; P.al_lambda = h->al_lambda; P.al_imu = h->al_imu;
+  const bool grav = h->hc.grav != 0.0;
+  P.recF = rec_fields(P.m, grav, P.al_lb != nullptr);
+  P.fLUU = REC_LU + P.m + (grav ? 4 : 0);
   return P;
 }
 
@@ -2905,26 +3045,14 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
-    if (!opt->line_search && h->st2 && P.N >= 8) {
-      // accept-always rollout: issue it in NSEG segments and re-linearise every finished segment on
-      // the library's second stream meanwhile (disjoint CU masks, see tolg_create)
-      static const int nseg_env = getenv("TOLG_OVERLAP_SEGS") ? atoi(getenv("TOLG_OVERLAP_SEGS")) : 4;
-      const int NSEG = nseg_env < 2 ? 2 : (nseg_env > 32 ? 32 : nseg_env);
-      hipStream_t sr = h->st_roll ? h->st_roll : st;
-      if (h->st_roll) {
-        if (hipEventRecord(h->seg_ev[NSEG + 1], st) != hipSuccess) return TOLG_E_LAUNCH;
-        if (hipStreamWaitEvent(sr, h->seg_ev[NSEG + 1], 0) != hipSuccess) return TOLG_E_LAUNCH;
+    if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
+        opt->schedule != TOLG_SCHED_SPLIT) {
+      // accept-always nonlinear rollout and the re-linearisation of the new trajectory in one launch
+      {
+        Timed t(h, st, 1);
+        hipLaunchKernelGGL((k_rollout_lin<M, 3>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P);
+        LAUNCH_CHECK();
       }
-      for (int sg = 0; sg < NSEG; sg++) {
-        const int i0 = (int)((long)P.N * sg / NSEG), i1 = (int)((long)P.N * (sg + 1) / NSEG);
-        if ((rc = run_rollout_ms<M>(h, P, sr, 1.0, opt->rollout_linear, 1, i0, i1))) return rc;
-        if (hipEventRecord(h->seg_ev[sg], sr) != hipSuccess) return TOLG_E_LAUNCH;
-        if (hipStreamWaitEvent(h->st2, h->seg_ev[sg], 0) != hipSuccess) return TOLG_E_LAUNCH;
-        const int k1 = (sg == NSEG - 1) ? P.N + 1 : i1;  // the last segment also takes the terminal knot
-        if ((rc = run_linearize<M>(h, P, h->st2, P.cand, P.cand_u, P.cur, P.cur_u, 1, i0, k1 - i0))) return rc;
-      }
-      if (hipEventRecord(h->seg_ev[NSEG], h->st2) != hipSuccess) return TOLG_E_LAUNCH;
-      if (hipStreamWaitEvent(st, h->seg_ev[NSEG], 0) != hipSuccess) return TOLG_E_LAUNCH;
       hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
       continue;

@@ -158,8 +158,10 @@ class BatchedTrackingILQR:
 
     def solve_begin(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
                     tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10, histories=True,
-                    out: Optional[FitResult] = None) -> FitResult:
-        """_initial_guess + first _linearization; leaves the batch resident in HBM."""
+                    out: Optional[FitResult] = None, schedule="auto") -> FitResult:
+        """_initial_guess + first _linearization; leaves the batch resident in HBM.
+        schedule: "auto" (rollout and re-linearisation fused in one launch where the mode allows it) or
+        "split" (separate launches); launch structure only, same algorithm."""
         x0_q = self._dev(x0_q, (-1, 16))
         B = x0_q.shape[0]
         x0_xi = self._dev(x0_xi, (B, 6))
@@ -171,7 +173,8 @@ class BatchedTrackingILQR:
             out = self._alloc_result(B, K, histories)
         o = _capi.Options(_capi.MODE_MS if mode == "ms" else _capi.MODE_SS, K, int(bool(line_search)),
                           int(rollout == "linear"), float(tol_grad_norm), float(tol_d_norm),
-                          float(max_reg if max_reg else 0.0))
+                          float(max_reg if max_reg else 0.0),
+                          {"auto": _capi.SCHED_AUTO, "split": _capi.SCHED_SPLIT}[schedule], 0)
         with torch.cuda.device(self.device):
             rc = self.lib.tolg_solve_begin(self._h, C.byref(o), B, _ptr(x0_q), _ptr(x0_xi), _ptr(us_init),
                                            _ptr(out.J_hist), _ptr(out.grad_hist), _ptr(out.defect_hist),
@@ -205,11 +208,11 @@ class BatchedTrackingILQR:
 
     def fit_batch(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
                   tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10,
-                  histories=True, out: Optional[FitResult] = None) -> FitResult:
+                  histories=True, out: Optional[FitResult] = None, schedule="auto") -> FitResult:
         """B independent fits (the reference's joblib fan-out, visualization/perturb_all_compute.py:240).
         Inputs may be numpy arrays or tensors already on the device; outputs are device tensors."""
         self.solve_begin(x0_q, x0_xi, us_init, mode, n_iterations, tol_grad_norm, tol_d_norm, line_search, rollout,
-                         max_reg, histories, out)
+                         max_reg, histories, out, schedule)
         self.solve_iterate(n_iterations)
         return self.solve_end()
 

@@ -93,6 +93,9 @@ def se3_tracking(B, N=200, R_scale=1e-5, seed=SEED):
 def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED):
     """Config 5: DroneDynamics on the first N+1 knots of path_dense_random_columns_4obj (dt=0.004)."""
     q_ref, xi_ref, dt = load_reference("drone_columns_n400")
+    if not 1 <= N <= q_ref.shape[0] - 1:
+        raise ValueError("path_dense_random_columns_4obj (stored part) has %d knots: horizon N must be in [1, %d]"
+                         % (q_ref.shape[0], q_ref.shape[0] - 1))
     q_ref, xi_ref = q_ref[: N + 1], xi_ref[: N + 1]
     Q = np.diag([25.0, 25, 25, 10, 10, 10, 1, 1, 1, 1, 1, 1])
     prob = TrackingProblem("drone", inertia(), dt, Q, np.eye(4) * R_scale, 1.5 * Q, q_ref, xi_ref)
@@ -129,6 +132,9 @@ def so3_tracking(B=1, N=100, seed=SEED):
     x0 = (q_ref[0], xi_ref[0]); members b > 0 are perturbed in rotation / angular velocity."""
     from .solver import embed_so3
     R_ref, w_ref, dt = load_reference("so3_8shape_n249")
+    if not 1 <= N <= R_ref.shape[0] - 1:
+        raise ValueError("path_3dpendulum_8shape has %d knots: horizon N must be in [1, %d]"
+                         % (R_ref.shape[0], R_ref.shape[0] - 1))
     R_ref, w_ref = R_ref[: N + 1], w_ref[: N + 1]
     Q6 = np.diag([10.0, 10, 10, 1, 1, 1])
     prob = embed_so3(np.diag([0.5, 0.7, 0.9]), dt, Q6, np.eye(3) * 1e-5, 10 * Q6, R_ref, w_ref)
