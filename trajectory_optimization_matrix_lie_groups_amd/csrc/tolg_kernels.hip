@@ -449,7 +449,10 @@ TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
 // the tracking error to REC_D, nothing is read from knot i+1).  next_state() returns the state of knot
 // i + 1 (called once, late, and only for ms == 1 on a non-terminal knot).
 // ------------------------------------------------------------------------------------------------
-template <int M, class CT, class NextFn>
+// CLOSED: the caller guarantees x_{i+1} = f(x_i, u_i) by construction (the fused rollout, whose step is exactly
+// that): the defect is zero and is not recomputed (the reference obtains rounding noise of ~1e-16 per entry here).
+// Exp / Log and the Jacobian coefficients use the series forms of tolg_lie.h inside their convergence domains.
+template <int M, bool CLOSED = false, class CT, class NextFn>
 TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const State& S, const double (&u)[M],
                        NextFn next_state) {
   const bool term = (i == P.N);
@@ -461,7 +464,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
     Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
     Xr.t = v3(r[4], r[5], r[6]);
     V3 ew, ev;
-    se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+    se3_log_fast(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
     // weights: l_xx switches to P at the terminal knot; l and l_x too, except for the SO3 cost which
     // keeps Q there (traopt_cost.py:434-438, :480-483 vs :530-531)
     const bool so3 = so3_family(C.kind);
@@ -473,8 +476,8 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
     double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
     double th2 = dot(ew, ew);
     double Ji[9], Qr[9], T1[9], Bm[9], Rr[9], Tr[9], Ja[9], Jb[9];
-    ljacinv33(neg(ew), ljacinv_coef(th2), Ji);  // Jr^-1(w) = Jl^-1(-w)
-    Q33(neg(ev), neg(ew), so3_coef(th2, true), Qr);
+    ljacinv33(neg(ew), ljacinv_coef_fast(th2), Ji);  // Jr^-1(w) = Jl^-1(-w)
+    Q33(neg(ev), neg(ew), so3_coef_fast(th2, true), Qr);
     mul33(Ji, Qr, T1);
     mul33(T1, Ji, Bm);  // rjacinv lower-left block = -Bm
     q_to_R(Xr.q, Rr);
@@ -582,9 +585,9 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
   if (term) return;
   // ---------------- dynamics Jacobian blocks (traopt_dynamics.py:802-837, :1416-1469)
   V3 wd = dt * S.w, vd = dt * S.v;
-  SO3Coef kc = so3_coef(dot(wd, wd), true);
+  SO3Coef kc = so3_coef_fast(dot(wd, wd), true);
   Pose E;
-  E.q = so3_exp(wd);
+  E.q = so3_exp_fast(wd);
   E.t = ljac_apply(wd, kc, vd);
   {
     // Ad(Exp(tau))^-1 = Ad(E^-1) = [[Ri,0],[[ti]x Ri, Ri]]
@@ -685,7 +688,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
     store_state(P, P.cand, i, b, F);
     return;
   }
-  if (ms) {
+  if (ms && !CLOSED) {
     State F = dyn_f<M>(C, S, u);
     State Sn = next_state();
     V3 dw, dv;
@@ -1956,13 +1959,15 @@ struct RStamps { unsigned long long acc[8], t; };
 #endif
 // STORE: the writer lane stores u^_i and x^_{i+1} to the candidate arrays; otherwise the caller takes them
 // (un_out and the return value) -- the fused rollout hands them to its linearisation wavefronts through LDS.
-template <int M, bool LINEAR, bool ALPHA1, int PK, bool STORE, class CT>
+// load_in(R): requests this step's gains and controls (from HBM, or from the LDS input ring of the fused kernel).
+template <int M, bool LINEAR, bool ALPHA1, int PK, bool STORE, class CT, class LoadFn>
 TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
-                         unsigned sB, double alpha, const State& So, const State& Sn, double (&un_out)[M] RST_PARAM) {
+                         unsigned sB, double alpha, const State& So, const State& Sn, double (&un_out)[M],
+                         LoadFn load_in RST_PARAM) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp;
   RSTAMP(0)
   RollIn<M> R;
-  roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R);  // in flight while Log runs
+  load_in(R);  // in flight while Log runs
   __builtin_amdgcn_sched_barrier(0);
   RSTAMP(1)
   // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
@@ -2076,11 +2081,13 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   for (int i = i0; i < i1; i += 2) {
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un_ RST_ARG);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un_,
+                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R); } RST_ARG);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un_ RST_ARG);
+    Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un_,
+                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i + 1, b, q, vb, sB, R); } RST_ARG);
   }
 #ifdef TOLG_STAMPS
   if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
@@ -2089,35 +2096,46 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
 
 // ------------------------------------------------------------------------------------------------
 // K3 + K1 fused: the accept-always MS iteration (line_search=False, rollout='nonlinear': the setting of
-// every benchmark_*.py) rolls out and re-linearises in ONE launch.  A workgroup owns 16 trajectories:
-// wavefront 0 is the sequential rollout above (four lanes per trajectory), wavefronts 1..NH are
-// linearisation helpers.  The rollout is a dependent chain on one of the CU's four SIMDs and leaves the
-// other three idle; the linearisation of knot i needs only (x^_i, u^_i, x^_{i+1}), i.e. it can start one
-// step behind the rollout.  Wave 0 therefore publishes every new state / control into an LDS ring instead
-// of storing it to HBM, and the helpers -- 64 lanes = 4 consecutive knots x 16 trajectories per pass, each
-// helper taking every NH-th group of four knots -- run lin_knot on them, write the knot records and commit
-// the new trajectory to P.cur in place.  That is safe: knot i of P.cur / P.cur_u is overwritten only after
-// step i of the rollout has completed, which consumed its (prefetched) old value; nothing else reads it.
-// No candidate trajectory is written or re-read (3 x 125 MB per iteration at 4096 x 200), and the separate
-// K1 launch disappears from the critical path (one helper pass, ~7 us, remains as a tail).
+// every benchmark_*.py) rolls out and re-linearises in ONE launch.  A 256-thread workgroup owns 16
+// trajectories and runs one wavefront on each SIMD of its CU:
+//   wave 0  the sequential rollout (roll_step above, four lanes per trajectory).  A dependent chain that
+//           leaves three SIMDs of the CU idle -- and, here, issues no vector-memory instruction at all;
+//   wave 1  the loader: streams the gains, controls and nominal states of the knots ahead of wave 0 from
+//           HBM into an LDS input ring with LDS-DMA (global_load_lds_dwordx4: no registers, 1 KB per
+//           instruction), up to RL_DEPTH knots ahead.  Wave 0 reads them with ds_read: its chain no longer sees HBM
+//           latency, nor the address-path queueing behind the helpers' record stores (with wave 0 loading
+//           from HBM itself the fused launch took 0.43 ms, the rollout alone 0.28: profiles/r02_*);
+//   waves 2, 3  linearisation helpers: the linearisation of knot i needs only (x^_i, u^_i, x^_{i+1}), so
+//           it can run one step behind the rollout.  Wave 0 publishes every new state / control into an LDS
+//           state ring instead of storing it to HBM; a helper pass takes 64 lanes = 4 consecutive knots x 16
+//           trajectories through lin_knot (helper h owns every second group of four knots), writes the knot
+//           records and commits the new trajectory to P.cur / P.cur_u in place.
+// In-place is safe: knot i of P.cur / P.cur_u is overwritten only after rollout step i has completed, and
+// the loader fetched the old value before that step could start; nothing else reads it during the launch.
+// No candidate trajectory is written or re-read, and the separate K1 launch leaves the critical path (one
+// helper pass, ~7 us, remains as a tail).
 //
-// Synchronisation is LDS only (one workgroup = one CU): LDS operations of a wave execute in order, so
-// "data writes, then counter write" needs no fence, and the s_barrier-free polling keeps wave 0's record /
-// gain prefetches in flight.  sync[0] = number of rollout steps completed (states 0..sync[0] and controls
-// 0..sync[0]-1 are in the ring); sync[1+h] = groups helper h has finished.  Wave 0 never waits for a helper
-// except to reuse a ring slot (the helpers are ~3x faster than the rollout, so it does not happen); a
-// helper waits only for wave 0: no cyclic wait.  Every poll loop is bounded: a stuck counter ends the
-// kernel with TOLG_ST_INTERNAL instead of hanging the GPU.
+// Synchronisation is LDS only (one workgroup = one CU), without s_barrier: LDS operations of a wave execute
+// in order, so "data, then counter" needs no fence on the producer side; LDS-DMA data is published only
+// after the loader's own counted s_waitcnt vmcnt has retired it.  sync[0] = rollout steps completed
+// (states 0..sync[0], controls 0..sync[0]-1 are in the state ring); sync[1] = knots whose inputs are in the
+// input ring; sync[2+h] = groups helper h has finished.  Wait-for graph: loader and helpers wait for wave 0;
+// wave 0 waits for the loader (which then depends only on steps wave 0 has already completed) and for a
+// helper only to reuse a state-ring slot (same argument): no cycle.  Every poll loop is bounded: a stuck
+// counter ends the kernel with TOLG_ST_INTERNAL instead of hanging the GPU.
 // ------------------------------------------------------------------------------------------------
-enum { RL_RING = 24, RL_PAIRS = 10, RL_POLLS = 1 << 21 };  // ring slots (knots); 16-byte field pairs per knot: 7 state + 3 control
-TOLG_DEV bool rl_wait_ge(volatile int* p, int v) {
+enum { RL_RING = 24, RL_PAIRS = 10, RL_DEPTH = 5, RL_NH = 2, RL_POLLS = 1 << 21 };
+// the counters are accessed through an LDS-address-space pointer: a volatile access through a generic pointer
+// becomes a flat load / store followed by s_waitcnt vmcnt(0), which would drain the poller's own memory queue
+typedef volatile __attribute__((address_space(3))) int* rl_sync_t;
+TOLG_DEV bool rl_wait_ge(rl_sync_t p, int v) {
   for (int n = 0; n < RL_POLLS; n++) {
     if (*p >= v) return true;
     __builtin_amdgcn_s_sleep(4);
   }
   return false;
 }
-// ring slot layout: [pair][trajectory][2] doubles, state fields 0..12 (+ padding) in pairs 0..6, controls in 7..9
+// state ring slot: [pair][trajectory][2] doubles, state fields 0..12 (+ padding) in pairs 0..6, controls in 7..9
 TOLG_DEV void rl_put_state(double* slot, int tt, const State& S) {
   f64x2* p = reinterpret_cast<f64x2*>(slot) + tt;
   p[0 * 16] = f64x2{S.X.q.x, S.X.q.y}; p[1 * 16] = f64x2{S.X.q.z, S.X.q.w}; p[2 * 16] = f64x2{S.X.t.x, S.X.t.y};
@@ -2134,11 +2152,55 @@ TOLG_DEV State rl_get_state(const double* slot, int tt) {
   S.v = v3(f.x, f.y, g.x);
   return S;
 }
-template <int M, int NH>
-__global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
+// input ring slot (bytes): the gains of the workgroup's four 4-trajectory groups exactly as they lie in GK
+// (contiguous), then 13 rows of 16 nominal-state values, then M rows of 16 controls (rows of P.cur / P.cur_u)
+template <int M>
+struct RlIn {
+  enum { GSZ = 13 * (M / 2) * 64, GAINS = 4 * GSZ, STATE = 13 * 128, CTRL = M * 128, SLOT = GAINS + STATE + CTRL,
+         NDMA = (GAINS + 1023) / 1024 + 2 + 1 };  // LDS-DMA instructions per knot
+};
+// one 16-byte-per-lane LDS-DMA: lane l copies 16 bytes from gsrc (its own address) to LDS byte address lds_dst + 16 l.
+// In asm, so that the compiler keeps no vmcnt bookkeeping for it (it would drain the DMA queue before every LDS poll);
+// M0, the DMA's LDS base, is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5).
+TOLG_DEV void rl_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int M>
+TOLG_DEV void rl_in_load(const char* slot, int tt, int q, RollIn<M>& R) {
+  const int qp = (2 * q < M) ? q : M / 2 - 1;  // lanes past the last row pair re-read it (their product is unused)
+  const char* g = slot + (tt >> 2) * RlIn<M>::GSZ + qp * 64 + (tt & 3) * 16;
+#pragma unroll
+  for (int k = 0; k < 13; k++) {
+    const f64x2 w = *reinterpret_cast<const f64x2*>(g + k * (M / 2) * 64);
+    R.G[0][k] = w.x; R.G[1][k] = w.y;
+  }
+  const double* u = reinterpret_cast<const double*>(slot + RlIn<M>::GAINS + RlIn<M>::STATE) + tt;
+#pragma unroll
+  for (int a = 0; a < M; a++) R.u[a] = u[a * 16];
+}
+template <int M>
+TOLG_DEV State rl_in_state(const char* slot, int tt) {
+  const double* x = reinterpret_cast<const double*>(slot + RlIn<M>::GAINS) + tt;
+  State S;
+  S.X.q.x = x[0]; S.X.q.y = x[16]; S.X.q.z = x[32]; S.X.q.w = x[48];
+  S.X.t = v3(x[64], x[80], x[96]);
+  S.w = v3(x[112], x[128], x[144]);
+  S.v = v3(x[160], x[176], x[192]);
+  return S;
+}
+template <int M>
+__global__ __launch_bounds__(256) void k_rollout_lin(Params P) {
+  typedef RlIn<M> IN;
   const DConsts& C = *(const DConsts*)P.c;
-  __shared__ double ring[RL_RING][RL_PAIRS * 16 * 2];
-  __shared__ int sync[4];
+  // One LDS object, carved by hand: the input ring first -- the LDS-DMA base register M0 is used with its
+  // classic 16-bit range, so every DMA destination stays below 64 KB -- then the state ring, then the counters.
+  static_assert(RL_DEPTH * IN::SLOT <= 65536 && IN::SLOT % 16 == 0, "LDS-DMA destinations must stay below 64 KB");
+  __shared__ __attribute__((aligned(16))) char lds[RL_DEPTH * IN::SLOT + RL_RING * RL_PAIRS * 256 + 32];
+  char (*inring)[IN::SLOT] = reinterpret_cast<char (*)[IN::SLOT]>(lds);
+  double (*ring)[RL_PAIRS * 32] = reinterpret_cast<double (*)[RL_PAIRS * 32]>(lds + RL_DEPTH * IN::SLOT);
+  int* sync = reinterpret_cast<int*>(lds + RL_DEPTH * IN::SLOT + RL_RING * RL_PAIRS * 256);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b0 = blockIdx.x * 16, N = P.N;
   {
@@ -2147,26 +2209,35 @@ __global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
     if (bb >= P.Bp) bb = P.Bp - 1;
     if (!__any(P.active[bb] != 0)) return;
   }
-  if (threadIdx.x < 4) sync[threadIdx.x] = (threadIdx.x == 0) ? -1 : 0;
+  if (threadIdx.x < 8) sync[threadIdx.x] = (threadIdx.x == 0) ? -1 : 0;
   __syncthreads();
-  volatile int* vs = sync;
+  const rl_sync_t vs = (rl_sync_t)sync;
   const unsigned sB = (unsigned)P.Bp * 8u;
   if (wave == 0) {
-    // ---------------- the rollout (k_rollout<M, false, true, 0>, results to the ring)
+    // ---------------- the rollout (k_rollout<M, false, true, 0> with LDS in place of HBM on both sides)
     int b = b0 + (lane >> 2);
     const int q = lane & 3, tt = lane >> 2;
-    if (b >= P.Bp) b = P.Bp - 1;  // quads past the batch replay the last trajectory; the helpers ignore their slots
+    if (b >= P.Bp) b = P.Bp - 1;  // quads past the batch compute on whatever the loader fetched; the helpers ignore their slots
     const bool writer = q == 0;
     const unsigned vb = (unsigned)b * 8u;
-    State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+    bool ok = true;
+    int loaded = 0;  // last value seen of sync[1]
+    auto need_inputs = [&](int knots) -> bool {  // wait until the inputs of knots 0 .. knots-1 are in the input ring
+      if (loaded >= knots) return true;
+      if (!rl_wait_ge(vs + 1, knots)) return false;
+      loaded = vs[1];
+      asm volatile("" ::: "memory");
+      return true;
+    };
+    if (!need_inputs(N < 2 ? N : 2)) { if (writer && b0 + tt < P.Bp) P.status[b0 + tt] = TOLG_ST_INTERNAL; return; }
+    State Sn = rl_in_state<M>(inring[0], tt);  // x^_0 = x_0
     if (writer) rl_put_state(ring[0], tt, Sn);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) vs[0] = 0;
     const DynK DK = dynk_load(C);
-    State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+    State Sa = Sn, Sb = Sn;
     double un[M];
-    bool ok = true;
 #ifdef TOLG_STAMPS
     RStamps ST;
     for (int k = 0; k < 8; k++) ST.acc[k] = 0;
@@ -2183,33 +2254,42 @@ __global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) vs[0] = i + 1;
     };
-    // Ring back-pressure, checked once per eight steps for the eight slots ahead (a poll is an LDS round trip
-    // on the critical chain): steps i .. i+7 overwrite the slots of knots up to `old` = i + 8 - RL_RING, which
+    // State-ring back-pressure, checked once per eight steps for the eight slots ahead (a poll is an LDS round
+    // trip on the critical chain): steps i .. i+7 overwrite the slots of knots up to `old` = i + 8 - RL_RING, which
     // is safe once every group of four knots up to the one holding `old` has been linearised (a group also
-    // reads the first state of the next group).  Helper h owns groups h, h + NH, ...: it must have finished
-    // (old/4 - h) / NH + 1 of them.
+    // reads the first state of the next group).  Helper h owns groups h, h + RL_NH, ...: it must have finished
+    // (old/4 - h) / RL_NH + 1 of them.
     auto slot_free = [&](int i) -> bool {
+#ifdef TOLG_EXP_NOLIN
+      return true;
+#endif
       if ((i & 7) != 0 || i + 8 < RL_RING) return true;
       const int go = (i + 8 - RL_RING) / 4;
 #pragma unroll
-      for (int h = 0; h < NH; h++)
-        if (go >= h && !rl_wait_ge(vs + 1 + h, (go - h) / NH + 1)) return false;
+      for (int h = 0; h < RL_NH; h++)
+        if (go >= h && !rl_wait_ge(vs + 2 + h, (go - h) / RL_NH + 1)) return false;
+      return true;
+    };
+    // one step: the nominal state of the NEXT knot is read from the input ring at the top of the step (one
+    // knot ahead, as the HBM version prefetched it), this knot's gains / controls inside roll_step
+    auto step = [&](int i, const State& So, State& Snext) -> bool {
+      if (!slot_free(i)) return false;
+      if (i + 1 < N) {
+        if (!need_inputs(i + 2)) return false;
+        Snext = rl_in_state<M>(inring[(i + 1) % RL_DEPTH], tt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const char* slot = inring[i % RL_DEPTH];
+      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i, b, q, writer, vb, sB, 1.0, So, Sn, un,
+                                               [&](RollIn<M>& R) { rl_in_load<M>(slot, tt, q, R); } RST_ARG);
+      finish_step(i);
+      RSTAMP(7)
       return true;
     };
     for (int i = 0; i < N; i += 2) {
-      if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ok = slot_free(i))) break;
-      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i, b, q, writer, vb, sB, 1.0, Sa, Sn, un RST_ARG);
-      finish_step(i);
-      RSTAMP(7)
+      if (!(ok = step(i, Sa, Sb))) break;
       if (i + 1 >= N) break;
-      if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ok = slot_free(i + 1))) break;
-      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i + 1, b, q, writer, vb, sB, 1.0, Sb, Sn, un RST_ARG);
-      finish_step(i + 1);
-      RSTAMP(7)
+      if (!(ok = step(i + 1, Sb, Sa))) break;
     }
 #ifdef TOLG_STAMPS
     if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
@@ -2217,12 +2297,69 @@ __global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
     if (!ok && writer && b0 + tt < P.Bp) P.status[b0 + tt] = TOLG_ST_INTERNAL;
     return;
   }
+  if (wave == 1) {
+    // ---------------- the loader: inputs of knot k go to slot k % RL_DEPTH once step k - RL_DEPTH has completed
+    const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp, gStride = (size_t)13 * M * P.Bp;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const int ntraj = (P.Bp - b0 < 16) ? P.Bp - b0 : 16;              // Bp is a multiple of 4
+    const int gchunks = (ntraj / 4) * (IN::GSZ / 16);                 // 16-byte pieces of gains this workgroup owns
+    auto issue = [&](int k) {
+      const unsigned dst = lds0 + (unsigned)(k % RL_DEPTH) * IN::SLOT;
+      const char* gk = reinterpret_cast<const char*>(P.GK + gStride * k + (size_t)(b0 >> 2) * 13 * M * 4);
+#pragma unroll
+      for (int c = 0; c < (IN::GAINS + 1023) / 1024; c++) {
+        // every instruction is issued whatever the workgroup's share (the counted vmcnt below relies on NDMA per
+        // knot): pieces of groups past the batch re-read piece 0 into their (unused) place
+        const int ch = c * 64 + lane;
+        if (ch < IN::GAINS / 16) rl_dma16(gk + (size_t)(ch < gchunks ? ch : 0) * 16, dst + c * 1024);
+      }
+      // states: 13 rows (fields) x 128 bytes; controls: M rows x 128 bytes; piece = 16 bytes, 8 per row
+      const char* xs = reinterpret_cast<const char*>(P.cur + stStride * k + b0);
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int ch = c * 64 + lane;
+        if (ch < 13 * 8) rl_dma16(xs + (size_t)(ch >> 3) * sB + (ch & 7) * 16, dst + IN::GAINS + c * 1024);
+      }
+      const char* us = reinterpret_cast<const char*>(P.cur_u + uStride * k + b0);
+      if (lane < M * 8) rl_dma16(us + (size_t)(lane >> 3) * sB + (lane & 7) * 16, dst + IN::GAINS + IN::STATE);
+    };
+    // Keep the ring as full as the rollout allows (knot k may be issued once step k - RL_DEPTH has completed) and
+    // publish every knot as soon as it has landed: the memory queue retires in order, so "at most n knots still
+    // outstanding" is a counted s_waitcnt with an immediate.
+    static_assert((RL_DEPTH - 1) * IN::NDMA <= 63, "vmcnt is a 6-bit counter");
+    int issued = 0, published = 0, idle = 0;
+    while (published < N) {
+      const int prod = vs[0];
+      bool did = false;
+      while (issued < N && (issued < RL_DEPTH || prod >= issued - RL_DEPTH + 1)) { issue(issued); issued++; did = true; }
+      if (published < issued) {
+        switch (issued - published - 1) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * IN::NDMA) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IN::NDMA) : "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * IN::NDMA) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * IN::NDMA) : "memory"); break;
+        }
+        published++;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) vs[1] = published;
+        idle = 0;
+      } else if (!did) {
+        if (++idle > RL_POLLS) return;  // wave 0 reports the failure
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    return;
+  }
   // ---------------- linearisation helpers: pass g covers knots 4g .. 4g+3 (lane / 16) of the 16 trajectories (lane % 16)
-  const int h = wave - 1, kk = lane >> 4, tt = lane & 15, b = b0 + tt;
+#ifdef TOLG_EXP_NOLIN
+  return;
+#endif
+  const int h = wave - 2, kk = lane >> 4, tt = lane & 15, b = b0 + tt;
   const bool mine = b < P.Bp && P.active[b < P.Bp ? b : 0] != 0;
   const int ngroups = (N + 1 + 3) / 4;
   int done = 0;
-  for (int g = h; g < ngroups; g += NH) {
+  for (int g = h; g < ngroups; g += RL_NH) {
     const int need = (4 * g + 4 < N) ? 4 * g + 4 : N;  // the last state this pass reads
     if (!rl_wait_ge(vs, need)) {
       if (mine && kk == 0) P.status[b] = TOLG_ST_INTERNAL;
@@ -2244,12 +2381,12 @@ __global__ __launch_bounds__(64 * (NH + 1)) void k_rollout_lin(Params P) {
         for (int a = 0; a < M; a++) P.cur_u[UIDX(a, i, b)] = u[a];
       }
       if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
-      lin_knot<M>(P, C, i, b, 1, S, u, [&]() { return rl_get_state(ring[(i + 1) % RL_RING], tt); });
+      lin_knot<M, true>(P, C, i, b, 1, S, u, [&]() { return S; });
     }
     done++;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every ring read of this pass has returned
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) vs[1 + h] = done;
+    if (lane == 0) vs[2 + h] = done;
   }
 }
 
@@ -3050,7 +3187,7 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       // accept-always nonlinear rollout and the re-linearisation of the new trajectory in one launch
       {
         Timed t(h, st, 1);
-        hipLaunchKernelGGL((k_rollout_lin<M, 3>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P);
+        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P);
         LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);

@@ -252,6 +252,58 @@ TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
   w = v3(c * q.x, c * q.y, c * q.z);
   v = ljacinv_apply(w, cl, X.t);
 }
+// Coefficients of V(w) and of the SE(3) Q block as series in th^2 (th^2 < 1: one time step of rotation, or a
+// tracking error below one radian; otherwise the closed forms).  (1 - cos t)/t^2 = sum (-1)^k t^2k/(2k+2)!,
+// (t - sin t)/t^3 = sum (-1)^k t^2k/(2k+3)!, (t^2 + 2 cos t - 2)/(2 t^4) = sum (-1)^k t^2k/(2k+4)!,
+// (2t - 3 sin t + t cos t)/(2 t^5) = sum (-1)^k (k+1) t^2k/(2k+5)!.  No sqrt / sincos / division, and none of the
+// cancellation the closed forms suffer for small angles.
+TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
+  if (!(th2 > TOLG_EPS && th2 < 1.0)) return so3_coef(th2, want_q);
+  const double A[10] = {0.5, -0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05, 2.755731922398589e-07,
+                        -2.08767569878681e-09, 1.1470745597729725e-11, -4.779477332387385e-14, 1.5619206968586225e-16,
+                        -4.110317623312165e-19};
+  const double B[10] = {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984, -2.7557319223985893e-06,
+                        2.505210838544172e-08, -1.6059043836821613e-10, 7.647163731819816e-13, -2.8114572543455206e-15,
+                        8.22063524662433e-18, -1.9572941063391263e-20};
+  SO3Coef k;
+  k.a = horner(A, th2);
+  k.b = horner(B, th2);
+  if (want_q) {
+    const double C2[9] = {0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07,
+                          2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16,
+                          4.110317623312165e-19};
+    const double C3[9] = {0.008333333333333333, -0.0003968253968253968, 8.267195767195768e-06, -1.0020843354176688e-07,
+                          8.029521918410807e-10, -4.58829823909189e-12, 1.9680200780418645e-14, -6.576508197299464e-17,
+                          1.7615646957052136e-19};
+    k.c1 = k.b;
+    k.c2 = horner(C2, th2);
+    k.c3 = horner(C3, th2);
+  } else {
+    k.c1 = k.c2 = k.c3 = 0;
+  }
+  return k;
+}
+// coefficient of W^2 in V(w)^-1 (ljacinv_coef) as the series of se3_log_fast, th^2 < 1/4
+TOLG_DEV double ljacinv_coef_fast(double th2) {
+  if (!(th2 > TOLG_EPS && th2 < 0.25)) return ljacinv_coef(th2);
+  const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
+                       2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
+                       8.586062056277845e-15};
+  return horner(L, th2);
+}
+// so3_exp with the half-angle series of se3_exp_fast
+TOLG_DEV Q4 so3_exp_fast(V3 w) {
+  const double th2 = dot(w, w);
+  if (!(th2 > TOLG_EPS && th2 < 1.0)) return so3_exp(w);
+  const double S[9] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
+                       -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
+  const double Cc[9] = {1.0, -1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600,
+                        -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+  const double y = 0.25 * th2, so = 0.5 * horner(S, y);
+  Q4 q;
+  q.x = so * w.x; q.y = so * w.y; q.z = so * w.z; q.w = horner(Cc, y);
+  return q;
+}
 TOLG_DEV Pose se3_compose(Pose A, Pose B) {
   Pose C;
   C.q = qmul(A.q, B.q);
