@@ -18,3 +18,7 @@ print("schedule:", sched)
 for n, v in zip(names, st):
     print("%-45s %8.0f cycles/knot  %5.1f %%" % (n, v / N, 100 * v / tot))
 print("total per knot %.0f (s_memtime ticks)" % (tot / N))
+if sched == "auto":
+    for h in range(2):
+        w, k, n = r.alpha_hist[81 + h, :3].cpu().numpy()
+        print("helper %d: %d passes, %.0f cycles per pass working, %.0f waiting for the rollout" % (h, n, k / max(n, 1), w / max(n, 1)))

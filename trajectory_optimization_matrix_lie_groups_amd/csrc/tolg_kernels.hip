@@ -2359,13 +2359,22 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P) {
   const bool mine = b < P.Bp && P.active[b < P.Bp ? b : 0] != 0;
   const int ngroups = (N + 1 + 3) / 4;
   int done = 0;
+#ifdef TOLG_STAMPS
+  unsigned long long hs_wait = 0, hs_work = 0, hs_t = __builtin_amdgcn_s_memtime();
+#endif
   for (int g = h; g < ngroups; g += RL_NH) {
     const int need = (4 * g + 4 < N) ? 4 * g + 4 : N;  // the last state this pass reads
+#ifdef TOLG_STAMPS
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); hs_work += t_ - hs_t; hs_t = t_; }
+#endif
     if (!rl_wait_ge(vs, need)) {
       if (mine && kk == 0) P.status[b] = TOLG_ST_INTERNAL;
       return;
     }
     asm volatile("" ::: "memory");
+#ifdef TOLG_STAMPS
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); hs_wait += t_ - hs_t; hs_t = t_; }
+#endif
     const int i = 4 * g + kk;
     if (mine && i <= N) {
       const double* slot = ring[i % RL_RING];
@@ -2388,6 +2397,13 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P) {
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) vs[2 + h] = done;
   }
+#ifdef TOLG_STAMPS
+  if (blockIdx.x == 5 && lane == 0 && P.alpha_hist) {
+    P.alpha_hist[(size_t)(81 + h) * P.max_iter + 0] = (double)hs_wait;
+    P.alpha_hist[(size_t)(81 + h) * P.max_iter + 1] = (double)hs_work;
+    P.alpha_hist[(size_t)(81 + h) * P.max_iter + 2] = (double)done;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
