@@ -123,6 +123,12 @@ int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const 
 int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream);
 int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
                    int32_t* d_status, int32_t* d_converged, void* stream);
+/* Number of trajectories of the solve in flight that are still being iterated (not converged, not stopped by
+ * a status), written to d_count[0] on `stream`.  The library never synchronises, so tolg_solve_batch always
+ * enqueues max_iter iterations (finished trajectories are masked, finished workgroups exit at once); a caller
+ * that wants the early exit of traopt_controller.py:2528-2532 issues the iterations in slices and reads this
+ * count between them (BatchedTrackingILQR.fit_batch does). */
+int tolg_solve_active_count(tolg_handle_t h, int32_t* d_count, void* stream);
 /* Same export without ending the solve: what the per-iteration on_iteration callback of
  * traoptlibrary/traopt_controller.py:2621-2626 needs (current xs, us) when a caller wants it. */
 int tolg_solve_peek(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,

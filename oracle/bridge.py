@@ -120,6 +120,8 @@ def fit(prob, x0_q, x0_xi, us_init, mode="ms", max_iter=200, tol_grad=1e-6, tol_
 
 def fit_batch(prob, x0_q, x0_xi, us_init, mode="ms", max_iter=20, tol_grad=0.0, tol_defect=0.0,
               line_search=False, rollout="nonlinear", max_reg=1e10, threads=None):
+    """B independent fits on `threads` OpenMP threads (None: the OpenMP default).  The returned dict's
+    "threads" is the size of the parallel region that actually ran."""
     B = x0_q.shape[0]
     N, m = prob.N, prob.m
     o = Options(max_iter, tol_grad, tol_defect, int(line_search), int(rollout == "linear"), max_reg)
@@ -128,13 +130,14 @@ def fit_batch(prob, x0_q, x0_xi, us_init, mode="ms", max_iter=20, tol_grad=0.0, 
     xs_q = np.zeros((B, N + 1, 4, 4)); xs_xi = np.zeros((B, N + 1, 6)); us = np.zeros((B, N, m))
     J_hist = np.full((B, K), np.nan); grad_hist = np.full((B, K + 1), np.nan); defect_hist = np.full((B, K + 1), np.nan)
     iters = np.zeros(B, np.int32); status = np.zeros(B, np.int32); conv = np.zeros(B, np.int32)
-    if threads is not None:
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-    lib().tolg_oracle_fit_batch(int(mode == "ms"), C.byref(prob.c), C.byref(o), B, _p(x0_q), _p(x0_xi), _p(us_init),
-                                _p(xs_q), _p(xs_xi), _p(us), _p(J_hist), _p(grad_hist), _p(defect_hist),
-                                iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip), conv.ctypes.data_as(_ip))
+    used = lib().tolg_oracle_fit_batch(int(mode == "ms"), C.byref(prob.c), C.byref(o), B, _p(x0_q), _p(x0_xi),
+                                       _p(us_init), _p(xs_q), _p(xs_xi), _p(us), _p(J_hist), _p(grad_hist),
+                                       _p(defect_hist), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip),
+                                       conv.ctypes.data_as(_ip), int(threads or 0))
+    if used < 0:
+        raise RuntimeError("oracle fit_batch failed (singular inertia matrix)")
     return dict(xs_q=xs_q, xs_xi=xs_xi, us=us, J_hist=J_hist, grad_hist=grad_hist, defect_hist=defect_hist,
-                iters=iters, status=status, converged=conv)
+                iters=iters, status=status, converged=conv, threads=int(used))
 
 
 def lin_backward(prob, xs_q, xs_xi, us, ms=True, mu=1.0, delta=2.0, max_reg=1e10):

@@ -23,6 +23,7 @@
  * quaternion (x, y, z, w) as scipy/manif store it.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1019,13 +1020,28 @@ typedef struct {
 static const int MS_ALPHAS = 20, SS_ALPHAS = 13;
 
 /* iLQR_Tracking_SE3_MS.fit (traopt_controller.py:2443-2639) */
+static int ms_fit_ws(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
+                     const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h,
+                     const dyn_cache *cp, ws_t *wp);
 int tolg_oracle_ms_fit(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
                        const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h) {
   dyn_cache c;
   ws_t w;
-  int N = p->N, m = p->m, rc = dyn_init(p, &c);
+  int rc = dyn_init(p, &c);
   if (rc) return rc;
-  ws_alloc(&w, N, m);
+  ws_alloc(&w, p->N, p->m);
+  rc = ms_fit_ws(p, o, x0_q, x0_xi, us_init, xs_q, xs_xi, us, h, &c, &w);
+  ws_free(&w);
+  dyn_free(&c);
+  return rc;
+}
+/* the same with the dynamics cache and the workspace of the caller (the batch driver keeps one per thread) */
+static int ms_fit_ws(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
+                     const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h,
+                     const dyn_cache *cp, ws_t *wp) {
+#define c (*cp)
+#define w (*wp)
+  int N = p->N, m = p->m;
   w.mu = 1.0; w.delta = 2.0;
   memcpy(w.us, us_init, sizeof(double) * (size_t)(N * m));
   /* _initial_guess (:3123-3136) */
@@ -1093,19 +1109,33 @@ int tolg_oracle_ms_fit(const tolg_problem *p, const tolg_options *o, const doubl
   memcpy(xs_q, w.xq, sizeof(double) * (size_t)(16 * (N + 1)));
   memcpy(xs_xi, w.xxi, sizeof(double) * (size_t)(6 * (N + 1)));
   memcpy(us, w.us, sizeof(double) * (size_t)(N * m));
-  ws_free(&w);
-  dyn_free(&c);
   return 0;
+#undef c
+#undef w
 }
 
 /* iLQR_Tracking_SE3.fit (traopt_controller.py:1880-2013) */
+static int ss_fit_ws(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
+                     const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h,
+                     const dyn_cache *cp, ws_t *wp);
 int tolg_oracle_ss_fit(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
                        const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h) {
   dyn_cache c;
   ws_t w;
-  int N = p->N, m = p->m, rc = dyn_init(p, &c);
+  int rc = dyn_init(p, &c);
   if (rc) return rc;
-  ws_alloc(&w, N, m);
+  ws_alloc(&w, p->N, p->m);
+  rc = ss_fit_ws(p, o, x0_q, x0_xi, us_init, xs_q, xs_xi, us, h, &c, &w);
+  ws_free(&w);
+  dyn_free(&c);
+  return rc;
+}
+static int ss_fit_ws(const tolg_problem *p, const tolg_options *o, const double *x0_q, const double *x0_xi,
+                     const double *us_init, double *xs_q, double *xs_xi, double *us, tolg_history *h,
+                     const dyn_cache *cp, ws_t *wp) {
+#define c (*cp)
+#define w (*wp)
+  int N = p->N, m = p->m;
   w.mu = 1.0; w.delta = 2.0;
   memcpy(w.us, us_init, sizeof(double) * (size_t)(N * m));
   /* _init_rollout (:2015-2028) */
@@ -1146,42 +1176,58 @@ int tolg_oracle_ss_fit(const tolg_problem *p, const tolg_options *o, const doubl
   memcpy(xs_q, w.xq, sizeof(double) * (size_t)(16 * (N + 1)));
   memcpy(xs_xi, w.xxi, sizeof(double) * (size_t)(6 * (N + 1)));
   memcpy(us, w.us, sizeof(double) * (size_t)(N * m));
-  ws_free(&w);
-  dyn_free(&c);
   return 0;
+#undef c
+#undef w
 }
 
 /* Batch driver: B independent fits (the reference's joblib fan-out,
- * visualization/perturb_all_compute.py:240-250), one trajectory per OpenMP thread.  Histories are
- * [B][max_iter(+1)] row-major. */
+ * visualization/perturb_all_compute.py:240-250), trajectories dealt to `threads` OpenMP threads (<= 0: the
+ * OpenMP default); every thread owns one dynamics cache, workspace and scratch history for all its
+ * trajectories.  Histories are [B][max_iter(+1)] row-major.  Returns the number of threads the parallel
+ * region actually ran with (< 0: error). */
 int tolg_oracle_fit_batch(int mode_ms, const tolg_problem *p, const tolg_options *o, int B,
                           const double *x0_q, const double *x0_xi, const double *us_init,
                           double *xs_q, double *xs_xi, double *us, double *J_hist, double *grad_hist,
-                          double *defect_hist, int *iters, int *status, int *converged) {
-  int N = p->N, m = p->m, K = o->max_iter;
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int b = 0; b < B; b++) {
+                          double *defect_hist, int *iters, int *status, int *converged, int threads) {
+  int N = p->N, m = p->m, K = o->max_iter, used = 1, err = 0;
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+  {
+    dyn_cache c;
+    ws_t w;
     tolg_history h;
-    h.J_hist = J_hist + (size_t)b * K;
-    h.grad_hist = grad_hist + (size_t)b * (K + 1);
-    h.defect_hist = defect_hist + (size_t)b * (K + 1);
-    h.alpha_hist = malloc(sizeof(double) * (size_t)K);
-    h.mu_hist = malloc(sizeof(double) * (size_t)K);
+    int ok = dyn_init(p, &c) == 0;
+    if (ok) ws_alloc(&w, N, m);
+    h.alpha_hist = malloc(sizeof(double) * (size_t)(K + 1));
+    h.mu_hist = malloc(sizeof(double) * (size_t)(K + 1));
     h.J_lin = malloc(sizeof(double) * (size_t)(K + 1));
-    h.trial_J = malloc(sizeof(double) * (size_t)K * 20);
-    h.n_trials = malloc(sizeof(int) * (size_t)K);
-    if (mode_ms)
-      tolg_oracle_ms_fit(p, o, x0_q + 16 * (size_t)b, x0_xi + 6 * (size_t)b, us_init + (size_t)b * N * m,
-                         xs_q + (size_t)b * 16 * (N + 1), xs_xi + (size_t)b * 6 * (N + 1),
-                         us + (size_t)b * N * m, &h);
-    else
-      tolg_oracle_ss_fit(p, o, x0_q + 16 * (size_t)b, x0_xi + 6 * (size_t)b, us_init + (size_t)b * N * m,
-                         xs_q + (size_t)b * 16 * (N + 1), xs_xi + (size_t)b * 6 * (N + 1),
-                         us + (size_t)b * N * m, &h);
-    iters[b] = h.n_iters; status[b] = h.status; converged[b] = h.converged;
+    h.trial_J = malloc(sizeof(double) * (size_t)(K + 1) * 20);
+    h.n_trials = malloc(sizeof(int) * (size_t)(K + 1));
+#pragma omp single
+    used = omp_get_num_threads();
+    if (!ok) {
+#pragma omp atomic write
+      err = 1;
+    }
+#pragma omp for schedule(dynamic, 1)
+    for (int b = 0; b < B; b++) {
+      if (!ok) continue;
+      h.J_hist = J_hist + (size_t)b * K;
+      h.grad_hist = grad_hist + (size_t)b * (K + 1);
+      h.defect_hist = defect_hist + (size_t)b * (K + 1);
+      if (mode_ms)
+        ms_fit_ws(p, o, x0_q + 16 * (size_t)b, x0_xi + 6 * (size_t)b, us_init + (size_t)b * N * m,
+                  xs_q + (size_t)b * 16 * (N + 1), xs_xi + (size_t)b * 6 * (N + 1), us + (size_t)b * N * m, &h, &c, &w);
+      else
+        ss_fit_ws(p, o, x0_q + 16 * (size_t)b, x0_xi + 6 * (size_t)b, us_init + (size_t)b * N * m,
+                  xs_q + (size_t)b * 16 * (N + 1), xs_xi + (size_t)b * 6 * (N + 1), us + (size_t)b * N * m, &h, &c, &w);
+      iters[b] = h.n_iters; status[b] = h.status; converged[b] = h.converged;
+    }
     free(h.alpha_hist); free(h.mu_hist); free(h.J_lin); free(h.trial_J); free(h.n_trials);
+    if (ok) { ws_free(&w); dyn_free(&c); }
   }
-  return 0;
+  return err ? -1 : used;
 }
 
 /* ---- element-level exports for unit tests -------------------------------------------------- */

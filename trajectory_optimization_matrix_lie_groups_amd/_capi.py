@@ -25,7 +25,7 @@ class Options(C.Structure):
 
 _lib = None
 SYMBOLS = ["tolg_workspace_bytes", "tolg_create", "tolg_destroy", "tolg_solve_batch", "tolg_solve_begin",
-           "tolg_solve_iterate", "tolg_solve_end", "tolg_solve_peek", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
+           "tolg_solve_iterate", "tolg_solve_end", "tolg_solve_peek", "tolg_solve_active_count", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
            "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version"]
 
 
@@ -58,6 +58,8 @@ def load():
     lib.tolg_solve_end.argtypes = [vp, dp, dp, dp, ip, ip, ip, vp]
     lib.tolg_solve_peek.restype = C.c_int
     lib.tolg_solve_peek.argtypes = [vp, dp, dp, dp, ip, ip, ip, vp]
+    lib.tolg_solve_active_count.restype = C.c_int
+    lib.tolg_solve_active_count.argtypes = [vp, ip, vp]
     lib.tolg_set_al.restype = C.c_int
     lib.tolg_set_al.argtypes = [vp, dp, dp, dp, dp]
     lib.tolg_al_update.restype = C.c_int

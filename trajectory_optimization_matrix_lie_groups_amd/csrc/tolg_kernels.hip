@@ -2832,6 +2832,13 @@ __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restri
     if (kk) kk[bn * P.m + u] = P.GK[GKIDX(i, u, b, 12)];
   }
 }
+// number of trajectories still being iterated (integer atomics: order-independent)
+__global__ void k_active_count(Params P, int* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool a = b < P.B && P.active[b] != 0;
+  const unsigned long long m = __ballot(a);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
 __global__ void k_export_scalars(Params P, double* J, double* dn, double* grad, double* mu_delta, int* iters,
                                  int* status, int* conv) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2995,7 +3002,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   memset(&c, 0, sizeof c);
   c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
   memcpy(c.J, prob->J, sizeof c.J);
-  if (host_inv6(prob->J, c.Jinv)) { delete h; return TOLG_E_SINGULAR; }
+  if (host_inv6(prob->J, c.Jinv)) { tolg_destroy(h); return TOLG_E_SINGULAR; }
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.Ib[3 * i + j] = prob->J[6 * i + j];
   c.mass = prob->J[6 * 4 + 4];                      // traopt_dynamics.py:663
   c.grav = (prob->kind == TOLG_DYN_SE3 || prob->kind == TOLG_DYN_SO3) ? 0.0 : 9.8;  // traopt_dynamics.py:1245, :466
@@ -3013,7 +3020,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   // "J: Inertia matrix, diag(I_b, m * I_3)"; G in f_x is built from Ib and m only)
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
-      if (prob->J[6 * i + j + 3] != 0.0 || prob->J[6 * (i + 3) + j] != 0.0) { delete h; return TOLG_E_ARG; }
+      if (prob->J[6 * i + j + 3] != 0.0 || prob->J[6 * (i + 3) + j] != 0.0) { tolg_destroy(h); return TOLG_E_ARG; }
       c.Jv[3 * i + j] = prob->J[6 * (i + 3) + j + 3];
       c.Ibinv[3 * i + j] = c.Jinv[6 * i + j];
       c.Jvinv[3 * i + j] = c.Jinv[6 * (i + 3) + j + 3];
@@ -3054,7 +3061,7 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   memset(&h->P, 0, sizeof h->P);
   carve_all(prob, h->Bp_max, h->ws, &h->P, &dc);
   h->P.N = prob->N; h->P.m = prob->m;
-  if (hipMemcpyAsync(dc, &h->hc, sizeof(Consts), hipMemcpyHostToDevice, st) != hipSuccess) { delete h; return TOLG_E_LAUNCH; }
+  if (hipMemcpyAsync(dc, &h->hc, sizeof(Consts), hipMemcpyHostToDevice, st) != hipSuccess) { tolg_destroy(h); return TOLG_E_LAUNCH; }
   int N = prob->N;
   hipLaunchKernelGGL(k_pack_ref, dim3((N + 1 + 63) / 64), dim3(64), 0, st, N, d_q_ref, d_xi_ref,
                      const_cast<double*>(h->P.ref));
@@ -3073,9 +3080,9 @@ extern "C" void tolg_enable_timing(tolg_handle_t h, int32_t on) {
   if (!h) return;
   h->timing = on != 0;
   if (h->timing && h->ev.empty()) {
-    h->ev.resize(2 * 4096);
+    h->ev.resize(2 * 1024);
     for (auto& e : h->ev) (void)hipEventCreate(&e);
-    h->ev_kind.resize(4096);
+    h->ev_kind.resize(1024);
   }
   h->ev_used = 0;
 }
@@ -3084,7 +3091,14 @@ namespace {
 struct Timed {
   tolg_handle_s* h; hipStream_t st; int kind; bool on;
   Timed(tolg_handle_s* h_, hipStream_t s, int k) : h(h_), st(s), kind(k) {
-    on = h->timing && h->ev_used < h->ev_kind.size();
+    on = h->timing;
+    if (on && h->ev_used == h->ev_kind.size()) {  // grow the event pool: a long solve must not silently stop being timed
+      const size_t n = h->ev_kind.size() + 1024;
+      h->ev.resize(2 * n);
+      for (size_t i = 2 * h->ev_kind.size(); i < 2 * n; i++)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev.resize(2 * h->ev_kind.size()); on = false; break; }
+      if (on) h->ev_kind.resize(n);
+    }
     if (on) (void)hipEventRecord(h->ev[2 * h->ev_used], st);
   }
   ~Timed() {
@@ -3324,6 +3338,15 @@ extern "C" int tolg_solve_peek(tolg_handle_t h, double* d_xs_q, double* d_xs_xi,
   return solve_export(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream, false);
 }
 
+extern "C" int tolg_solve_active_count(tolg_handle_t h, int32_t* d_count, void* stream) {
+  if (!h || !h->running || !d_count) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(d_count, 0, sizeof(int32_t), st) != hipSuccess) return TOLG_E_LAUNCH;
+  hipLaunchKernelGGL(k_active_count, dim3((h->run.B + 255) / 256), dim3(256), 0, st, h->run, d_count);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
                                 const double* d_x0_xi, const double* d_us_init, double* d_xs_q, double* d_xs_xi,
                                 double* d_us, double* d_J_hist, double* d_grad_hist, double* d_defect_hist,
@@ -3361,7 +3384,8 @@ extern "C" int tolg_linearize_backward(tolg_handle_t h, int32_t ms, double max_r
                                        const double* d_xs_xi, const double* d_us, double* d_mu_delta, double* d_Fx,
                                        double* d_d, double* d_lx, double* d_lxx11, double* d_k, double* d_K,
                                        double* d_J, double* d_dnorm, double* d_grad, void* stream) {
-  if (!h || B < 1 || B > h->max_batch || !d_xs_q || !d_xs_xi || !d_us) return TOLG_E_ARG;
+  // uses the handle's workspace (k_pack_traj resets the trajectories, mu / delta, the masks): not during a solve
+  if (!h || h->running || B < 1 || B > h->max_batch || !d_xs_q || !d_xs_xi || !d_us) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
   P.max_reg = max_reg;
@@ -3409,7 +3433,7 @@ extern "C" int tolg_eval_knot(tolg_handle_t h, int32_t i, int32_t n, const doubl
 
 extern "C" int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear, double alpha, int32_t B,
                             double* d_xs_q_new, double* d_xs_xi_new, double* d_us_new, void* stream) {
-  if (!h || B < 1 || B > h->max_batch) return TOLG_E_ARG;
+  if (!h || h->running || B < 1 || B > h->max_batch) return TOLG_E_ARG;  // overwrites the candidate arrays
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
   int rc = (P.m == 4) ? run_rollout_ms<4>(h, P, st, alpha, rollout_linear, ms) : run_rollout_ms<6>(h, P, st, alpha, rollout_linear, ms);

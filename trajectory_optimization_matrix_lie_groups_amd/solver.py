@@ -189,6 +189,15 @@ class BatchedTrackingILQR:
             rc = self.lib.tolg_solve_iterate(self._h, int(n_iter), self._stream())
         _capi.check(rc, "tolg_solve_iterate")
 
+    def active_count(self) -> int:
+        """Trajectories of the solve in flight that are still being iterated (one small kernel + a host read)."""
+        if getattr(self, "_active_buf", None) is None:
+            self._active_buf = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_active_count(self._h, _ptr(self._active_buf), self._stream())
+        _capi.check(rc, "tolg_solve_active_count")
+        return int(self._active_buf.item())
+
     def solve_peek(self) -> FitResult:
         """Export the trajectories in flight (xs, us, iters, status) without ending the solve."""
         out = self._inflight[0]
@@ -208,12 +217,27 @@ class BatchedTrackingILQR:
 
     def fit_batch(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
                   tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10,
-                  histories=True, out: Optional[FitResult] = None, schedule="auto") -> FitResult:
+                  histories=True, out: Optional[FitResult] = None, schedule="auto", check_every=16) -> FitResult:
         """B independent fits (the reference's joblib fan-out, visualization/perturb_all_compute.py:240).
-        Inputs may be numpy arrays or tensors already on the device; outputs are device tensors."""
+        Inputs may be numpy arrays or tensors already on the device; outputs are device tensors.
+        The iterations are issued in slices of `check_every`; between slices the number of trajectories still
+        iterating is read back and the loop stops when it reaches zero (the early exit of
+        traopt_controller.py:2528-2532 for the whole batch).  check_every=0, or tolerances of zero, issue all
+        n_iterations without a host read."""
         self.solve_begin(x0_q, x0_xi, us_init, mode, n_iterations, tol_grad_norm, tol_d_norm, line_search, rollout,
                          max_reg, histories, out, schedule)
-        self.solve_iterate(n_iterations)
+        n = int(n_iterations)
+        can_stop = check_every and (tol_grad_norm > 0 or line_search or mode == "ss")
+        if not can_stop:
+            self.solve_iterate(n)
+        else:
+            done = 0
+            while done < n:
+                step = min(int(check_every), n - done)
+                self.solve_iterate(step)
+                done += step
+                if done < n and self.active_count() == 0:
+                    break
         return self.solve_end()
 
     # ------------------------------------------------------------------------------------------

@@ -2,9 +2,11 @@
 
 BaseController :14-40, iLQR_Tracking_SE3 :1831-2349, iLQR_Tracking_SE3_MS :2352-3136,
 AL_iLQR_Tracking_SE3_MS :3139-3293.  ``fit`` keeps the reference's signature, return tuple and
-callback protocol for one trajectory; ``fit_batch`` (new) solves B initial states at once.  Both
-dispatch the whole iteration loop to the HIP extension; there is no per-knot Python loop and no CPU
-fallback."""
+callback protocol for one trajectory; ``fit_batch`` (new) solves B initial states at once.  For the
+closed-form plugin classes both dispatch the whole iteration loop to the HIP extension (no per-knot
+Python loop, no CPU twin of the kernels).  Any other plugin -- a subclass, an overridden method, a
+hand-written BaseDynamics / BaseCost -- takes the generic per-knot callback loop of _generic_lie.py,
+as SURVEY.md §8b prescribes."""
 import abc
 import warnings
 
@@ -26,6 +28,13 @@ class BaseController():
     @abc.abstractmethod
     def fit(self, x0, us_init, *args, **kwargs):
         raise NotImplementedError
+
+
+def _fusable(dynamics, cost):
+    """True when (dynamics, cost) is one of the closed-form triples the HIP path implements: exact types only,
+    a subclass may override any method (SURVEY.md §8b 'What calls it')."""
+    base = cost.cost if isinstance(cost, ALConstrainedCost) else cost
+    return type(dynamics) in _KIND and type(base) is SE3TrackingQuadraticGaussNewtonCost
 
 
 def _problem_of(dynamics, cost):
@@ -124,58 +133,79 @@ class _FusedController(BaseController):
             if al:
                 solver.set_al(None)
 
+    def _is_fusable(self):
+        return _fusable(self.dynamics, self.cost)
+
+    def _fit_generic(self, x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms):
+        """Plugins outside the closed-form set: per-knot callback loop on the host (_generic_lie.py)."""
+        from ._generic_lie import GenericLieILQR
+        opt = self._options()
+        g = GenericLieILQR(self.dynamics, self.cost, self.N, "ms" if ms else "ss", max_reg=opt["max_reg"],
+                           line_search=opt["line_search"], rollout=opt["rollout"])
+        out = g.fit(x0, us_init, getattr(self, "_q_ref", None), getattr(self, "_xi_ref", None), n_iterations,
+                    tol_grad_norm, tol_d_norm, on_iteration, self._append_grad_on_convergence)
+        self._mu = g.mu
+        return out
+
     # one trajectory, iteration by iteration, so that the callback sees what the reference shows it
     def _fit_single(self, x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms):
+        if not self._is_fusable():
+            return self._fit_generic(x0, us_init, n_iterations, tol_grad_norm, tol_d_norm, on_iteration, ms)
         q0, xi0 = _bridge.split_state(x0)
         solver = self._get_solver(1)
         us0 = np.asarray(us_init, float).reshape(1, self.N, self._action_size)
         J_hist, xs_hist, us_hist, grad_hist, defect_hist = [], [], [], [], []
         al = self._attach_al(solver, 1)
-        res = solver.solve_begin(q0, xi0, us0, mode=self._mode, n_iterations=n_iterations, tol_grad_norm=tol_grad_norm,
-                                 tol_d_norm=tol_d_norm, **self._options())
-        solver.solve_peek()
-        xs = _xs_list(_bridge.host(res.xs_q)[0], _bridge.host(res.xs_xi)[0])
-        us = _bridge.host(res.us)[0].copy()
-        xs_hist.append(list(xs))
-        us_hist.append(us.copy())
-        if ms:
-            defect_hist.append(float(res.defect_hist[0, 0]))
-        converged = False
-        for it in range(int(n_iterations)):
-            solver.solve_iterate(1)
+        begun = False
+        try:
+            res = solver.solve_begin(q0, xi0, us0, mode=self._mode, n_iterations=n_iterations,
+                                     tol_grad_norm=tol_grad_norm, tol_d_norm=tol_d_norm, **self._options())
+            begun = True
             solver.solve_peek()
-            iters, status, conv = int(res.iters[0]), int(res.status[0]), int(res.converged[0])
-            grad = float(res.grad_hist[0, it])
-            if not ms:
-                grad_hist.append(grad)  # SS appends inside fit (traopt_controller.py:1938)
-            if conv:  # gradient test fired: the reference breaks before the callback (:2528-2532, :1939-1942)
-                converged = True
-                if ms and self._append_grad_on_convergence:
-                    grad_hist.append(grad)
-                break
-            if status == 1:
-                warnings.warn(_MSG_MAXREG)
-            accepted = status != 2
             xs = _xs_list(_bridge.host(res.xs_q)[0], _bridge.host(res.xs_xi)[0])
             us = _bridge.host(res.us)[0].copy()
-            J_opt = float(res.J_hist[0, it])
-            alpha = float(res.alpha_hist[0, it])
-            mu = float(res.mu_hist[0, it])
-            self._mu = mu
-            if on_iteration:
-                if ms:  # 15 positional arguments (:2621-2626)
-                    on_iteration(it, xs, us, J_opt, accepted, converged, float(res.defect_hist[0, it + 1]), grad, alpha, mu,
-                                 J_hist, xs_hist, us_hist, grad_hist, defect_hist)
-                else:   # 12 positional arguments (:1996-2000)
-                    on_iteration(it, xs, us, J_opt, accepted, converged, grad, alpha, mu, J_hist, xs_hist, us_hist)
-            if not accepted:
-                warnings.warn(_MSG_NODESCENT)
-                break
-            if iters <= it:  # non-finite cost: the device froze this trajectory
-                break
-        solver.solve_end()
-        if al:
-            solver.set_al(None)
+            xs_hist.append(list(xs))
+            us_hist.append(us.copy())
+            if ms:
+                defect_hist.append(float(res.defect_hist[0, 0]))
+            converged = False
+            for it in range(int(n_iterations)):
+                solver.solve_iterate(1)
+                solver.solve_peek()
+                iters, status, conv = int(res.iters[0]), int(res.status[0]), int(res.converged[0])
+                grad = float(res.grad_hist[0, it])
+                if not ms:
+                    grad_hist.append(grad)  # SS appends inside fit (traopt_controller.py:1938)
+                if conv:  # gradient test fired: the reference breaks before the callback (:2528-2532, :1939-1942)
+                    converged = True
+                    if ms and self._append_grad_on_convergence:
+                        grad_hist.append(grad)
+                    break
+                if status == 1:
+                    warnings.warn(_MSG_MAXREG)
+                accepted = status != 2
+                xs = _xs_list(_bridge.host(res.xs_q)[0], _bridge.host(res.xs_xi)[0])
+                us = _bridge.host(res.us)[0].copy()
+                J_opt = float(res.J_hist[0, it])
+                alpha = float(res.alpha_hist[0, it])
+                mu = float(res.mu_hist[0, it])
+                self._mu = mu
+                if on_iteration:
+                    if ms:  # 15 positional arguments (:2621-2626)
+                        on_iteration(it, xs, us, J_opt, accepted, converged, float(res.defect_hist[0, it + 1]), grad, alpha, mu,
+                                     J_hist, xs_hist, us_hist, grad_hist, defect_hist)
+                    else:   # 12 positional arguments (:1996-2000)
+                        on_iteration(it, xs, us, J_opt, accepted, converged, grad, alpha, mu, J_hist, xs_hist, us_hist)
+                if not accepted:
+                    warnings.warn(_MSG_NODESCENT)
+                    break
+                if iters <= it:  # non-finite cost: the device froze this trajectory
+                    break
+        finally:  # a raising callback must not leave the handle mid-solve or the multipliers attached
+            if begun:
+                solver.solve_end()
+            if al:
+                solver.set_al(None)
         return xs, us, J_hist, xs_hist, us_hist, grad_hist, defect_hist
 
 
@@ -305,6 +335,9 @@ class AL_iLQR_Tracking_SE3_MS(BaseController):
 # SO(3) controllers: same algorithm, states are [SO3, SO3Tangent] objects (traopt_controller.py:526-1824)
 # ---------------------------------------------------------------------------------------------------
 class _FusedControllerSO3(_FusedController):
+    def _is_fusable(self):
+        return True  # the SO(3) controllers have no generic path: _get_solver rejects other plugin types
+
     def _get_solver(self, B):
         if self._solver is None or self._solver_batch < B:
             if type(self.dynamics) not in (SO3Dynamics, Pendulum3dDyanmics) or \
@@ -416,14 +449,32 @@ class PDViolationError(Exception):
     """Custom exception class for handling positive definite violation errors (traopt_controller.py:35-37)."""
 
 
-class iLQR(BaseController):
-    """Finite Horizon Iterative Linear Quadratic Regulator on a Euclidean state (traopt_controller.py:42-520),
-    with the true-DDP tensor terms when hessians=True (:487-490).
+class _Expansion:
+    """Second-order model of one rollout in stacked, homogeneous form.
 
-    Generic plugin path: any BaseDynamics / BaseCost works through the per-knot methods; AutoDiffDynamics /
-    AutoDiffCost additionally expose knot-batched derivatives, which _forward_rollout uses to evaluate the
-    N Jacobians of a rollout in one torch.func.vmap call instead of N Python calls.  The solver arithmetic
-    (NumPy, fp64) follows the reference line by line, including its line-search and regularisation rules."""
+    z = (x, u, 1): `G[i]` ((n+1) x (n+m+1)) maps z_i to (x_{i+1}, 1) to first order, `H[i]` ((n+m+1)^2) is the
+    Hessian of the stage cost in z with the gradient in its last row / column, `T[i]` (n x (n+m) x (n+m), DDP
+    only) the second derivative of the dynamics.  One backward sweep over these carries the value function
+    [[V_xx, V_x], [V_x^T, .]] and the adjoint of the control gradient together."""
+
+    __slots__ = ("xs", "J", "G", "H", "T", "HN", "fu", "n", "m")
+
+
+class iLQR(BaseController):
+    """Finite Horizon Iterative Linear Quadratic Regulator on a Euclidean state, with the true-DDP tensor terms
+    when hessians=True.  Same interface, acceptance rule, regularisation schedule and callback protocol as the
+    reference class (traopt_controller.py:42-520: `fit` :83-222, the 10 step sizes :118, the acceptance /
+    regularisation bookkeeping :160-207, the 12-argument callback :209-211); the arithmetic is organised
+    differently -- BASELINE config 1 is host plumbing here, not the hot path:
+
+    * derivatives of a whole rollout come from the knot-batched plugin methods (`AutoDiff*.batch`: one
+      torch.func.vmap call per quantity) when the plugin has them, per-knot calls otherwise;
+    * the backward pass is ONE sweep in homogeneous coordinates: Q = H_i + G_i^T V G_i (+ mu-regularised input
+      rows, + V_x . T_i for DDP) is a single congruence per knot, the gain block [K | k] one solve, the new value
+      function one Schur-type update -- and the adjoint p_t of the gradient test rides along as an extra vector,
+      the way the device kernel K2 carries it in a spare lane."""
+
+    _ALPHAS = 1.1 ** (-np.arange(10) ** 2)
 
     def __init__(self, dynamics, cost, N, max_reg=1e10, hessians=False):
         self.dynamics = dynamics
@@ -442,159 +493,148 @@ class iLQR(BaseController):
         self._k = np.zeros((N, self._action_size))
         self._K = np.zeros((N, self._action_size, self._state_size))
 
-    def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-3, on_iteration=None):
-        self._mu = 1.0
-        self._delta = self._delta_0
-        alphas = 1.1 ** (-np.arange(10) ** 2)
-        us = np.array(us_init, dtype=float)
-        k, K = self._k, self._K
-        J_hist, xs_hist, us_hist = [], [], []
-        changed = True
-        converged = False
-        alpha = alphas[0]
-        grad_wrt_input_norm = np.inf
-        for iteration in range(n_iterations):
-            accepted = False
-            if changed:
-                (xs, F_x, F_u, L, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu) = self._forward_rollout(x0, us)
-                J_opt = L.sum()
-                changed = False
-            try:
-                k, K = self._backward_pass(F_x, F_u, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu)
-                _, grad_wrt_input_norm = self._gradient_wrt_control(F_x, F_u, L_x, L_u)  # alpha independent (:166)
-                for alpha in alphas:
-                    xs_new, us_new = self._control(xs, us, k, K, alpha)
-                    J_new = self._trajectory_cost(xs_new, us_new)
-                    if grad_wrt_input_norm < tol_grad_norm:
-                        converged = True
-                        accepted = True
-                        break
-                    if J_new < J_opt:
-                        if np.abs((J_opt - J_new) / J_opt) < tol_J:
-                            converged = True
-                        J_opt = J_new
-                        xs = xs_new
-                        us = us_new
-                        changed = True
-                        self._delta = min(1.0, self._delta) / self._delta_0
-                        self._mu *= self._delta
-                        if self._mu <= self._mu_min:
-                            self._mu = 0.0
-                        accepted = True
-                        break
-            except np.linalg.LinAlgError as e:
-                warnings.warn(str(e))
-            if not accepted:
-                self._delta = max(1.0, self._delta) * self._delta_0
-                self._mu = max(self._mu_min, self._mu * self._delta)
-                if self._mu_max and self._mu >= self._mu_max:
-                    warnings.warn("exceeded max regularization term")
-                    break
-            if on_iteration:
-                on_iteration(iteration, xs, us, J_opt, accepted, converged, grad_wrt_input_norm, alpha, self._mu,
-                             J_hist, xs_hist, us_hist)
-            if converged:
-                break
-        self._k = k
-        self._K = K
-        self._nominal_xs = xs
-        self._nominal_us = us
-        return xs, us, J_hist, xs_hist, us_hist
+    # ---- plugin access: knot-batched when available ------------------------------------------------
+    def _stack(self, plugin, which, xs, us, shape, **kw):
+        N = us.shape[0]
+        if hasattr(plugin, "batch"):
+            return np.asarray(plugin.batch(which, xs[:N], us)).reshape((N,) + shape)
+        fn = getattr(plugin, which)
+        return np.stack([np.asarray(fn(xs[i], us[i], i, **kw)).reshape(shape) for i in range(N)])
 
-    def _control(self, xs, us, k, K, alpha=1.0):
-        xs_new = np.zeros_like(xs)
-        us_new = np.zeros_like(us)
-        xs_new[0] = xs[0].copy()
+    def _simulate(self, x0, us):
+        xs = np.empty((us.shape[0] + 1, self._state_size))
+        xs[0] = np.asarray(x0, dtype=float)
+        for i, u in enumerate(us):
+            xs[i + 1] = self.dynamics.f(xs[i], u, i)
+        return xs
+
+    def _trajectory_cost(self, xs, us):
+        stage = self._stack(self.cost, "l", xs, us, (), terminal=False)
+        return float(stage.sum()) + float(self.cost.l(xs[-1], None, self.N, terminal=True))
+
+    def _expand(self, xs, us):
+        n, m, N = self._state_size, self._action_size, self.N
+        dyn, cost = self.dynamics, self.cost
+        e = _Expansion()
+        e.xs, e.n, e.m = xs, n, m
+        fx = self._stack(dyn, "f_x", xs, us, (n, n))
+        e.fu = self._stack(dyn, "f_u", xs, us, (n, m))
+        e.G = np.zeros((N, n + 1, n + m + 1))
+        e.G[:, :n, :n] = fx
+        e.G[:, :n, n:n + m] = e.fu
+        e.G[:, n, n + m] = 1.0
+        kw = dict(terminal=False)
+        e.H = np.zeros((N, n + m + 1, n + m + 1))
+        e.H[:, :n, :n] = self._stack(cost, "l_xx", xs, us, (n, n), **kw)
+        lux = self._stack(cost, "l_ux", xs, us, (m, n), **kw)
+        e.H[:, n:n + m, :n] = lux
+        e.H[:, :n, n:n + m] = np.swapaxes(lux, 1, 2)
+        e.H[:, n:n + m, n:n + m] = self._stack(cost, "l_uu", xs, us, (m, m), **kw)
+        g = np.concatenate([self._stack(cost, "l_x", xs, us, (n,), **kw), self._stack(cost, "l_u", xs, us, (m,), **kw)], axis=1)
+        e.H[:, :n + m, n + m] = g
+        e.H[:, n + m, :n + m] = g
+        stage = self._stack(cost, "l", xs, us, (), **kw)
+        xN = xs[-1]
+        e.J = float(stage.sum()) + float(cost.l(xN, None, N, terminal=True))
+        e.HN = np.zeros((n + 1, n + 1))
+        e.HN[:n, :n] = cost.l_xx(xN, None, N, terminal=True)
+        e.HN[:n, n] = e.HN[n, :n] = cost.l_x(xN, None, N, terminal=True)
+        e.T = None
+        if self._use_hessians:
+            e.T = np.zeros((N, n, n + m, n + m))
+            fux = self._stack(dyn, "f_ux", xs, us, (n, m, n))
+            e.T[:, :, :n, :n] = self._stack(dyn, "f_xx", xs, us, (n, n, n))
+            e.T[:, :, n:, :n] = fux
+            e.T[:, :, :n, n:] = np.swapaxes(fux, 2, 3)
+            e.T[:, :, n:, n:] = self._stack(dyn, "f_uu", xs, us, (n, m, m))
+        return e
+
+    def _sweep(self, e, mu):
+        """Gains [K | k] of every knot and the mean norm of the control gradient dJ/du_t."""
+        n, m, N = e.n, e.m, self.N
+        V = e.HN.copy()                      # [[V_xx, V_x], [V_x^T, 0]]
+        p = e.HN[:n, n].copy()               # adjoint of the open-loop gradient
+        gains = np.empty((N, m, n + 1))
+        gsum = 0.0
+        for i in range(N - 1, -1, -1):
+            G, fu = e.G[i], e.fu[i]
+            Q = e.H[i] + G.T @ V @ G
+            if mu:                           # regularisation acts on the input rows only: F_u^T (V_xx + mu I) [F_x F_u]
+                Q[n:n + m, :n + m] += mu * (fu.T @ G[:n, :n + m])
+                Q[:n, n:n + m] = Q[n:n + m, :n].T
+            if e.T is not None:
+                Q[:n + m, :n + m] += np.tensordot(V[:n, n], e.T[i], axes=1)
+            gu = e.H[i][n:n + m, n + m] + fu.T @ p
+            gsum += float(np.linalg.norm(gu))
+            p = e.H[i][:n, n + m] + G[:n, :n].T @ p
+            Quu = Q[n:n + m, n:n + m]
+            Qua = np.concatenate([Q[n:n + m, :n], Q[n:n + m, n + m:]], axis=1)      # [Q_ux | Q_u]
+            Kk = -np.linalg.solve(Quu, Qua)
+            gains[i] = Kk
+            Qaa = np.empty((n + 1, n + 1))
+            Qaa[:n, :n] = Q[:n, :n]
+            Qaa[:n, n] = Qaa[n, :n] = Q[:n, n + m]
+            Qaa[n, n] = Q[n + m, n + m]
+            cross = Kk.T @ Qua
+            V = Qaa + Kk.T @ Quu @ Kk + cross + cross.T
+            V[:n, :n] = 0.5 * (V[:n, :n] + V[:n, :n].T)
+        return gains[:, :, n].copy(), gains[:, :, :n].copy(), gsum / N
+
+    def _closed_loop(self, xs, us, k, K, alpha):
+        xs_new, us_new = np.empty_like(xs), np.empty_like(us)
+        xs_new[0] = xs[0]
         for i in range(self.N):
-            us_new[i] = us[i] + alpha * k[i] + K[i].dot(xs_new[i] - xs[i])
+            us_new[i] = us[i] + alpha * k[i] + K[i] @ (xs_new[i] - xs[i])
             xs_new[i + 1] = self.dynamics.f(xs_new[i], us_new[i], i)
         return xs_new, us_new
 
-    def _trajectory_cost(self, xs, us):
-        if hasattr(self.cost, "batch"):
-            J = float(np.sum(self.cost.batch("l", xs[:-1], us)))
-        else:
-            J = sum(self.cost.l(x, u, i) for i, (x, u) in enumerate(zip(xs[:-1], us)))
-        return J + self.cost.l(xs[-1], None, self.N, terminal=True)
+    def _relax(self):
+        self._delta = min(1.0, self._delta) / self._delta_0
+        self._mu *= self._delta
+        if self._mu <= self._mu_min:
+            self._mu = 0.0
 
-    def _forward_rollout(self, x0, us):
-        n, m, N = self.dynamics.state_size, self.dynamics.action_size, us.shape[0]
-        xs = np.empty((N + 1, n))
-        xs[0] = np.asarray(x0, dtype=float)
-        for i in range(N):
-            xs[i + 1] = self.dynamics.f(xs[i], us[i], i)
-        dyn_b, cost_b = hasattr(self.dynamics, "batch"), hasattr(self.cost, "batch")
+    def _tighten(self):
+        self._delta = max(1.0, self._delta) * self._delta_0
+        self._mu = max(self._mu_min, self._mu * self._delta)
+        return bool(self._mu_max and self._mu >= self._mu_max)
 
-        def dyn(which, shape):
-            if dyn_b:
-                return self.dynamics.batch(which, xs[:-1], us).reshape((N,) + shape)
-            return np.stack([np.asarray(getattr(self.dynamics, which)(xs[i], us[i], i)).reshape(shape) for i in range(N)])
-
-        def cst(which, shape):
-            if cost_b:
-                return self.cost.batch(which, xs[:-1], us).reshape((N,) + shape)
-            return np.stack([np.asarray(getattr(self.cost, which)(xs[i], us[i], i, terminal=False)).reshape(shape)
-                             for i in range(N)])
-
-        F_x, F_u = dyn("f_x", (n, n)), dyn("f_u", (n, m))
-        F_xx = F_ux = F_uu = None
-        if self._use_hessians:
-            F_xx, F_ux, F_uu = dyn("f_xx", (n, n, n)), dyn("f_ux", (n, m, n)), dyn("f_uu", (n, m, m))
-        L = np.empty(N + 1)
-        L_x = np.empty((N + 1, n))
-        L_xx = np.empty((N + 1, n, n))
-        L[:N] = cst("l", ())
-        L_x[:N] = cst("l_x", (n,))
-        L_u = cst("l_u", (m,))
-        L_xx[:N] = cst("l_xx", (n, n))
-        L_ux = cst("l_ux", (m, n))
-        L_uu = cst("l_uu", (m, m))
-        x = xs[-1]
-        L[-1] = self.cost.l(x, None, N, terminal=True)
-        L_x[-1] = self.cost.l_x(x, None, N, terminal=True)
-        L_xx[-1] = self.cost.l_xx(x, None, N, terminal=True)
-        return xs, F_x, F_u, L, L_x, L_u, L_xx, L_ux, L_uu, F_xx, F_ux, F_uu
-
-    def _backward_pass(self, F_x, F_u, L_x, L_u, L_xx, L_ux, L_uu, F_xx=None, F_ux=None, F_uu=None):
-        V_x = L_x[-1]
-        V_xx = L_xx[-1]
-        k = np.empty_like(self._k)
-        K = np.empty_like(self._K)
-        for i in range(self.N - 1, -1, -1):
-            if self._use_hessians:
-                Q_x, Q_u, Q_xx, Q_ux, Q_uu = self._Q(F_x[i], F_u[i], L_x[i], L_u[i], L_xx[i], L_ux[i], L_uu[i], V_x,
-                                                     V_xx, F_xx[i], F_ux[i], F_uu[i])
-            else:
-                Q_x, Q_u, Q_xx, Q_ux, Q_uu = self._Q(F_x[i], F_u[i], L_x[i], L_u[i], L_xx[i], L_ux[i], L_uu[i], V_x,
-                                                     V_xx)
-            k[i] = -np.linalg.solve(Q_uu, Q_u)   # the reference tests is_pos_def here and carries on (:398-399)
-            K[i] = -np.linalg.solve(Q_uu, Q_ux)
-            V_x = Q_x + K[i].T.dot(Q_uu).dot(k[i])
-            V_x += K[i].T.dot(Q_u) + Q_ux.T.dot(k[i])
-            V_xx = Q_xx + K[i].T.dot(Q_uu).dot(K[i])
-            V_xx += K[i].T.dot(Q_ux) + Q_ux.T.dot(K[i])
-            V_xx = 0.5 * (V_xx + V_xx.T)
-        return np.array(k), np.array(K)
-
-    def _Q(self, f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx, f_xx=None, f_ux=None, f_uu=None):
-        Q_x = l_x + f_x.T.dot(V_x)
-        Q_u = l_u + f_u.T.dot(V_x)
-        Q_xx = l_xx + f_x.T.dot(V_xx).dot(f_x)
-        reg = self._mu * np.eye(self.dynamics.state_size)
-        Q_ux = l_ux + f_u.T.dot(V_xx + reg).dot(f_x)
-        Q_uu = l_uu + f_u.T.dot(V_xx + reg).dot(f_u)
-        if self._use_hessians:
-            Q_xx = Q_xx + np.tensordot(V_x, f_xx, axes=1)
-            Q_ux = Q_ux + np.tensordot(V_x, f_ux, axes=1)
-            Q_uu = Q_uu + np.tensordot(V_x, f_uu, axes=1)
-        return Q_x, Q_u, Q_xx, Q_ux, Q_uu
-
-    def _gradient_wrt_control(self, F_x, F_u, L_x, L_u):
-        g = np.zeros((self.N, self._action_size))
-        p = L_x[self.N]
-        g_norm_sum = 0
-        for t in range(self.N - 1, -1, -1):
-            g[t] = L_u[t] + np.matmul(F_u[t].T, p)
-            p = L_x[t] + np.matmul(F_x[t].T, p)
-            g_norm_sum = g_norm_sum + np.linalg.norm(g[t])
-        return g, g_norm_sum / self.N
+    def fit(self, x0, us_init, n_iterations=100, tol_J=1e-6, tol_grad_norm=1e-3, on_iteration=None):
+        self._mu, self._delta = 1.0, self._delta_0
+        us = np.array(us_init, dtype=float)
+        xs = self._simulate(x0, us)
+        J_hist, xs_hist, us_hist = [], [], []
+        k, K = self._k, self._K
+        model, grad, alpha, J_opt = None, np.inf, self._ALPHAS[0], None
+        for iteration in range(n_iterations):
+            if model is None:                # the trajectory moved: new expansion
+                model = self._expand(xs, us)
+                J_opt = model.J
+            accepted = converged = False
+            try:
+                k, K, grad = self._sweep(model, self._mu)
+                for alpha in self._ALPHAS:
+                    xs_try, us_try = self._closed_loop(xs, us, k, K, alpha)
+                    J_try = self._trajectory_cost(xs_try, us_try)
+                    if grad < tol_grad_norm:             # stationary: stop without moving
+                        accepted = converged = True
+                        break
+                    if J_try < J_opt:
+                        converged = abs((J_opt - J_try) / J_opt) < tol_J
+                        xs, us, J_opt, model = xs_try, us_try, J_try, None
+                        self._relax()
+                        accepted = True
+                        break
+            except np.linalg.LinAlgError as err:
+                warnings.warn(str(err))
+            if not accepted and self._tighten():
+                warnings.warn("exceeded max regularization term")
+                break
+            if on_iteration:
+                on_iteration(iteration, xs, us, J_opt, accepted, converged, grad, alpha, self._mu, J_hist, xs_hist,
+                             us_hist)
+            if converged:
+                break
+        self._k, self._K = k, K
+        self._nominal_xs, self._nominal_us = xs, us
+        return xs, us, J_hist, xs_hist, us_hist
