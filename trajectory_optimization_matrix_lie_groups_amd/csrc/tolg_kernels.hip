@@ -452,9 +452,11 @@ TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
 // CLOSED: the caller guarantees x_{i+1} = f(x_i, u_i) by construction (the fused rollout, whose step is exactly
 // that): the defect is zero and is not recomputed (the reference obtains rounding noise of ~1e-16 per entry here).
 // Exp / Log and the Jacobian coefficients use the series forms of tolg_lie.h inside their convergence domains.
+// lcost: where the stage cost goes instead of P.SC (the fused kernel sums the costs of its own trajectories itself,
+// from LDS; a CLOSED trajectory has no defect to sum either).
 template <int M, bool CLOSED = false, class CT, class NextFn>
 TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const State& S, const double (&u)[M],
-                       NextFn next_state) {
+                       NextFn next_state, double* lcost = nullptr) {
   const bool term = (i == P.N);
   const double dt = C.dt;
   // ---------------- cost: e = Log(X Xref^-1), J_e = Jr^-1(e) Ad(Xref)  (traopt_cost.py:659-839)
@@ -552,7 +554,8 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
         }
       }
     }
-    P.SC[(size_t)i * P.Bp + b] = l;
+    if (lcost) *lcost = l;
+    else P.SC[(size_t)i * P.Bp + b] = l;
     double WJ[36];
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -704,7 +707,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
 #pragma unroll
   for (int a = 0; a < 12; a++) d2 += d[a] * d[a];
   rec_run<REC_D, 12>(P, i, b, d);
-  P.SD[(size_t)i * P.Bp + b] = d2;
+  if (!(CLOSED && lcost)) P.SD[(size_t)i * P.Bp + b] = d2;
 }
 
 template <int M>
@@ -2191,13 +2194,19 @@ TOLG_DEV State rl_in_state(const char* slot, int tt) {
   return S;
 }
 template <int M>
-__global__ __launch_bounds__(256) void k_rollout_lin(Params P) {
+constexpr size_t rl_static_lds() { return (size_t)RL_DEPTH * RlIn<M>::SLOT + (size_t)RL_RING * RL_PAIRS * 256 + 32; }
+template <int M>
+__global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
   typedef RlIn<M> IN;
   const DConsts& C = *(const DConsts*)P.c;
   // One LDS object, carved by hand: the input ring first -- the LDS-DMA base register M0 is used with its
   // classic 16-bit range, so every DMA destination stays below 64 KB -- then the state ring, then the counters.
   static_assert(RL_DEPTH * IN::SLOT <= 65536 && IN::SLOT % 16 == 0, "LDS-DMA destinations must stay below 64 KB");
-  __shared__ __attribute__((aligned(16))) char lds[RL_DEPTH * IN::SLOT + RL_RING * RL_PAIRS * 256 + 32];
+  // ... and, in dynamic LDS behind it, the stage costs [N + 1][16]: the helper that finishes last sums the costs of
+  // the workgroup's trajectories in knot order and does the per-iteration bookkeeping (k_reduce's job in the split
+  // schedule).  rl_lds_bytes() is the total; the host falls back to the split schedule when it exceeds the CU's LDS.
+  __shared__ __attribute__((aligned(16))) char lds[rl_static_lds<M>()];
+  extern __shared__ __attribute__((aligned(16))) double lcost[];  // [N + 1][16], sized at launch
   char (*inring)[IN::SLOT] = reinterpret_cast<char (*)[IN::SLOT]>(lds);
   double (*ring)[RL_PAIRS * 32] = reinterpret_cast<double (*)[RL_PAIRS * 32]>(lds + RL_DEPTH * IN::SLOT);
   int* sync = reinterpret_cast<int*>(lds + RL_DEPTH * IN::SLOT + RL_RING * RL_PAIRS * 256);
@@ -2390,12 +2399,32 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P) {
         for (int a = 0; a < M; a++) P.cur_u[UIDX(a, i, b)] = u[a];
       }
       if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
-      lin_knot<M, true>(P, C, i, b, 1, S, u, [&]() { return S; });
+      lin_knot<M, true>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
     }
     done++;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every ring read of this pass has returned
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) vs[2 + h] = done;
+  }
+  // ---- the helper that finishes last: trajectory costs in knot order (the summation order of k_reduce), then the
+  // on_iteration bookkeeping of traopt_controller.py:2621-2626.  LDS operations of a wave execute in order, so the
+  // other helper's cost writes precede its arrival on the counter.
+  int last = 0;
+  if (lane == 0) last = __hip_atomic_fetch_add(&sync[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == RL_NH - 1;
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (last && mine && kk == 0) {
+    asm volatile("" ::: "memory");
+    double J = 0;
+    for (int i = 0; i <= N; i++) J += lcost[i * 16 + tt];
+    P.Jc[b] = J;
+    P.dn[b] = 0.0;  // closed by construction
+    if (b < P.B) {
+      if (P.J_hist) P.J_hist[(size_t)b * P.max_iter + it] = J;
+      if (P.defect_hist) P.defect_hist[(size_t)b * (P.max_iter + 1) + it + 1] = 0.0;
+      if (P.alpha_hist) P.alpha_hist[(size_t)b * P.max_iter + it] = P.ls_alpha[b];
+      P.iters[b] = it + 1;
+      if (!(J == J) || isinf(J)) { P.status[b] = TOLG_ST_NONFINITE; P.active[b] = 0; }
+    }
   }
 #ifdef TOLG_STAMPS
   if (blockIdx.x == 5 && lane == 0 && P.alpha_hist) {
@@ -2870,6 +2899,7 @@ struct tolg_handle_s {
   tolg_options run_opt;
   int run_it;         // iterations issued so far
   bool running;
+  int lds_per_block;  // hipDeviceAttributeMaxSharedMemoryPerBlock of the current device (160 KB on MI355X)
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
   // timing
   bool timing;
@@ -2998,6 +3028,16 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
   h->running = false;
   h->run_it = 0;
   h->al_lb = h->al_ub = h->al_lambda = h->al_imu = nullptr;
+  {
+    int dev = 0, lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) lds = 65536;
+    h->lds_per_block = lds;
+    // the fused kernel's dynamic LDS (cost table) comes on top of ~120 KB of static rings
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_lin<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_lin<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipGetLastError();
+  }
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
   c.kind = prob->kind; c.m = prob->m; c.N = prob->N; c.diagJ = 0; c.dt = prob->dt;
@@ -3212,17 +3252,16 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
+    const size_t dyn_lds = (size_t)(P.N + 1) * 16 * sizeof(double);
     if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
-        opt->schedule != TOLG_SCHED_SPLIT) {
+        opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + dyn_lds <= (size_t)h->lds_per_block) {
       // accept-always nonlinear rollout and the re-linearisation of the new trajectory in one launch
       {
         Timed t(h, st, 1);
-        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P);
+        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), dyn_lds, st, P, it);
         LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
-      LAUNCH_CHECK();
-      continue;
+      continue;  // the fused launch also sums the costs and does the bookkeeping of k_reduce
     } else if (!opt->line_search) {
       if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
     } else {
