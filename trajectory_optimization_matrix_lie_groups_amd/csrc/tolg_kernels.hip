@@ -1460,6 +1460,142 @@ TOLG_DEV void lu_solve(double (&A)[M][M], double (&x)[M]) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Q_uu (m x m, column c in lane c of the 16-lane row) is factored where it lies: right-looking L D L^T, pivot by
+// pivot, the rank-1 update of the trailing columns one DPP-fused multiply-add per row (the multiplier of column c,
+// Q[j][c] / d_j, is that lane's own).  Every lane then solves for its own right-hand side (its column of
+// [Q_ux | Q_u]) with the factor entries broadcast from the lanes that hold them.  Compared with the former
+// replicated Cholesky (21 broadcasts + a full factorisation in every lane) this is ~45 instructions and 70
+// registers less per knot; the pivots are those of the Cholesky factor squared, so the positive-definiteness test
+// (is_pos_def(Q_uu + Q_uu^T), traopt_utilis.py:320-329) is the same test: every pivot > 0.
+// ------------------------------------------------------------------------------------------------
+TOLG_DEV double rcp_nr(double d) {  // 1/d to double precision: v_rcp_f64 seed + two Newton steps
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+#ifndef TOLG_DPP_BUILTIN
+#define DFA(acc, p, q, L) "v_fmac_f64_dpp " acc ", " p ", " q " row_newbcast:" L " row_mask:0xf bank_mask:0xf\n\t"
+// a[i] += a[i]@lane J * w for the rows below pivot J
+template <int M, int J>
+TOLG_DEV void ldl_update(double (&a)[M], double w) {
+  constexpr int R = M - 1 - J;
+  if constexpr (R == 5)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%0", "%5", "%6") DFA("%1", "%1", "%5", "%6") DFA("%2", "%2", "%5", "%6")
+                     DFA("%3", "%3", "%5", "%6") DFA("%4", "%4", "%5", "%6")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]), "+v"(a[J + 5]) : "v"(w), "n"(J));
+  if constexpr (R == 4)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%0", "%4", "%5") DFA("%1", "%1", "%4", "%5") DFA("%2", "%2", "%4", "%5")
+                     DFA("%3", "%3", "%4", "%5")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]) : "v"(w), "n"(J));
+  if constexpr (R == 3)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%0", "%3", "%4") DFA("%1", "%1", "%3", "%4") DFA("%2", "%2", "%3", "%4")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]) : "v"(w), "n"(J));
+  if constexpr (R == 2)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%0", "%2", "%3") DFA("%1", "%1", "%2", "%3")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]) : "v"(w), "n"(J));
+  if constexpr (R == 1)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%0", "%1", "%2") : "+v"(a[J + 1]) : "v"(w), "n"(J));
+}
+// y += sum_{k < I} p@lane k * q[k]     (row I of a forward substitution: p = this lane's copy of factor row I)
+template <int M, int I>
+TOLG_DEV void ldl_fwd_row(double& y, double p, const double (&q)[M]) {
+  if constexpr (I == 1) asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "0") : "+v"(y) : "v"(p), "v"(q[0]));
+  if constexpr (I == 2)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "0") DFA("%0", "%1", "%3", "1") : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]));
+  if constexpr (I == 3)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "0") DFA("%0", "%1", "%3", "1") DFA("%0", "%1", "%4", "2")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]));
+  if constexpr (I == 4)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "0") DFA("%0", "%1", "%3", "1") DFA("%0", "%1", "%4", "2")
+                     DFA("%0", "%1", "%5", "3")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+  if constexpr (I == 5)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "0") DFA("%0", "%1", "%3", "1") DFA("%0", "%1", "%4", "2")
+                     DFA("%0", "%1", "%5", "3") DFA("%0", "%1", "%6", "4")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]));
+}
+// t += sum_{k > I} a[k]@lane I * x[k]  (row I of the back substitution: column I of the factor lives in lane I)
+template <int M, int I>
+TOLG_DEV void ldl_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
+  constexpr int R = M - 1 - I;
+  if constexpr (R == 1) asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%2", "%3") : "+v"(t) : "v"(a[I + 1]), "v"(x[I + 1]), "n"(I));
+  if constexpr (R == 2)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%3", "%5") DFA("%0", "%2", "%4", "%5")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(x[I + 1]), "v"(x[I + 2]), "n"(I));
+  if constexpr (R == 3)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%4", "%7") DFA("%0", "%2", "%5", "%7") DFA("%0", "%3", "%6", "%7")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(x[I + 1]), "v"(x[I + 2]), "v"(x[I + 3]), "n"(I));
+  if constexpr (R == 4)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%5", "%9") DFA("%0", "%2", "%6", "%9") DFA("%0", "%3", "%7", "%9")
+                     DFA("%0", "%4", "%8", "%9")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(x[I + 1]), "v"(x[I + 2]),
+                   "v"(x[I + 3]), "v"(x[I + 4]), "n"(I));
+  if constexpr (R == 5)
+    asm volatile("s_nop 1\n\t" DFA("%0", "%1", "%6", "%11") DFA("%0", "%2", "%7", "%11") DFA("%0", "%3", "%8", "%11")
+                     DFA("%0", "%4", "%9", "%11") DFA("%0", "%5", "%10", "%11")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(a[I + 5]), "v"(x[I + 1]),
+                   "v"(x[I + 2]), "v"(x[I + 3]), "v"(x[I + 4]), "v"(x[I + 5]), "n"(I));
+}
+#else
+template <int M, int J>
+TOLG_DEV void ldl_update(double (&a)[M], double w) {
+#pragma unroll
+  for (int i = J + 1; i < M; i++) a[i] += bcast<J>(a[i]) * w;
+}
+template <int M, int I>
+TOLG_DEV void ldl_fwd_row(double& y, double p, const double (&q)[M]) {
+  if constexpr (I > 0) y += bcast<0>(p) * q[0];
+  if constexpr (I > 1) y += bcast<1>(p) * q[1];
+  if constexpr (I > 2) y += bcast<2>(p) * q[2];
+  if constexpr (I > 3) y += bcast<3>(p) * q[3];
+  if constexpr (I > 4) y += bcast<4>(p) * q[4];
+}
+template <int M, int I>
+TOLG_DEV void ldl_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
+#pragma unroll
+  for (int k = I + 1; k < M; k++) t += bcast<I>(a[k]) * x[k];
+}
+#endif
+// In place: on return a[i] (i > c) of lane c holds column c of the factor times its pivot (L[i][c] d_c), rinv[j] =
+// 1 / d_j in every lane.  jl = lane index within the 16-lane row.  Returns "every pivot > 0".
+template <int M, int J = 0>
+TOLG_DEV bool ldl_factor(double (&a)[M], double (&rinv)[M], int jl, bool ok = true) {
+  const double d = bcast<J>(a[J]);
+  ok = ok && (d > 0.0);
+  rinv[J] = rcp_nr(ok ? d : 1.0);
+  if constexpr (J + 1 < M) {
+    // multiplier of this lane's column: -Q[J][c] / d_J for the columns right of the pivot, 0 for the others (their
+    // rows below J are already final factor entries and must not move)
+    const double w = (jl > J) ? -a[J] * rinv[J] : 0.0;
+    ldl_update<M, J>(a, w);
+    return ldl_factor<M, J + 1>(a, rinv, jl, ok);
+  } else {
+    return ok;
+  }
+}
+// x <- (L D L^T)^-1 x for this lane's right-hand side
+template <int M>
+TOLG_DEV void ldl_solve(const double (&a)[M], const double (&rinv)[M], double (&x)[M]) {
+  // forward, unit lower triangle: y_i = b_i - sum_{k<i} (a[i]@k / d_k) y_k; zn_k = -y_k / d_k is what the next stage needs too
+  double zn[M];
+  zn[0] = -x[0] * rinv[0];
+  if constexpr (M > 1) { ldl_fwd_row<M, 1>(x[1], a[1], zn); zn[1] = -x[1] * rinv[1]; }
+  if constexpr (M > 2) { ldl_fwd_row<M, 2>(x[2], a[2], zn); zn[2] = -x[2] * rinv[2]; }
+  if constexpr (M > 3) { ldl_fwd_row<M, 3>(x[3], a[3], zn); zn[3] = -x[3] * rinv[3]; }
+  if constexpr (M > 4) { ldl_fwd_row<M, 4>(x[4], a[4], zn); zn[4] = -x[4] * rinv[4]; }
+  if constexpr (M > 5) { ldl_fwd_row<M, 5>(x[5], a[5], zn); zn[5] = -x[5] * rinv[5]; }
+  // backward: x_i = y_i / d_i - (1 / d_i) sum_{k>i} a[k]@i x_k
+  x[M - 1] = -zn[M - 1];
+  if constexpr (M > 1) { double t = 0; ldl_bwd_row<M, M - 2>(t, a, x); x[M - 2] = -fma(rinv[M - 2], t, zn[M - 2]); }
+  if constexpr (M > 2) { double t = 0; ldl_bwd_row<M, M - 3>(t, a, x); x[M - 3] = -fma(rinv[M - 3], t, zn[M - 3]); }
+  if constexpr (M > 3) { double t = 0; ldl_bwd_row<M, M - 4>(t, a, x); x[M - 4] = -fma(rinv[M - 4], t, zn[M - 4]); }
+  if constexpr (M > 4) { double t = 0; ldl_bwd_row<M, M - 5>(t, a, x); x[M - 5] = -fma(rinv[M - 5], t, zn[M - 5]); }
+  if constexpr (M > 5) { double t = 0; ldl_bwd_row<M, M - 6>(t, a, x); x[M - 6] = -fma(rinv[M - 6], t, zn[M - 6]); }
+}
+
 // VARB: F_u differs from knot to knot (Pendulum3dDyanmics): its 3x3 block is read from REC_BU.
 // GRAV: the model has a gravity block A21 in F_x (Drone / RigidBody / Pendulum); SE3 / SO3 instantiate
 // without it and save its 18 per-lane coefficients (36 VGPRs in a kernel that already spills to AGPRs).
@@ -1692,11 +1828,12 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int r = 0; r < 6; r++) Qh[6 + r] += mW2 * kBW[r];
     STAMP(3)
     // ---- regularised Q_ux | Q_u, Q_uu; PD test; gains   (traopt_controller.py:2964-2995, :3052-3060)
-    double Quh[M], Kh[M], Ls[M][M], dinv[M], Qrep[M][M];
+    double Quh[M], Kh[M], Uf[M], rinv[M];
     bool use_lu = false;
-    // one regularisation attempt with the current mu: Q_ux | Q_u, Q_uu, Cholesky of its symmetric part
-    auto attempt = [&]() -> bool {
-      const double muA = m12 * mu;
+    double mu_used = 0.0;  // the mu of the last attempt (the max-regularisation exit solves with that attempt's matrices)
+    // Q_ux | Q_u (Quh) and Q_uu (column per lane) for a given mu
+    auto build_quu = [&](double mu_, double (&Quu)[M]) {
+      const double muA = m12 * mu_;
       // X' = (V + mu I) F_x, rows 6..11 (B has no other non-zero rows); vector columns: w
       double Xp[6];
 #pragma unroll
@@ -1719,7 +1856,6 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         T[u] = m12 * tt;
       }
       // Q_uu = 2R + T B: column per lane (lanes 0..M-1): Quu[u] += T[u]@lane(6+k) * B[6+k][lane]
-      double Quu[M];
 #pragma unroll
       for (int u = 0; u < M; u++) Quu[u] = kRB[u] + ((j == u) ? luu_i : 0.0);
       if constexpr (DIAGJ && M == 6 && !VARB) {
@@ -1736,20 +1872,12 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
         quu_acc<M, 6>(Quu, T, kBW[0]); quu_acc<M, 7>(Quu, T, kBW[1]); quu_acc<M, 8>(Quu, T, kBW[2]);
         quu_acc<M, 9>(Quu, T, kBW[3]); quu_acc<M, 10>(Quu, T, kBW[4]); quu_acc<M, 11>(Quu, T, kBW[5]);
       }
-      // replicate the lower triangle (row u, columns c <= u) to every lane; the symmetric part is
-      // what is_pos_def(Q_uu + Q_uu^T) tests (traopt_utilis.py:320-329)
-#pragma unroll
-      for (int u = 0; u < M; u++) {
-        Qrep[u][0] = bcast<0>(Quu[u]);
-        if (u >= 1) Qrep[u][1] = bcast<1>(Quu[u]);
-        if (u >= 2) Qrep[u][2] = bcast<2>(Quu[u]);
-        if (u >= 3) Qrep[u][3] = bcast<3>(Quu[u]);
-        if constexpr (M > 4) {
-          if (u >= 4) Qrep[u][4] = bcast<4>(Quu[u]);
-          if (u >= 5) Qrep[u][5] = bcast<5>(Quu[u]);
-        }
-      }
-      return chol_sym<M>(Ls, Qrep, dinv);
+    };
+    // one regularisation attempt with the current mu: the matrices above, Q_uu factored in place (L D L^T)
+    auto attempt = [&]() -> bool {
+      mu_used = mu;
+      build_quu(mu, Uf);
+      return ldl_factor<M>(Uf, rinv, j);
     };
     // regularisation schedule (traopt_controller.py:2975-2995); returns true when this knot is settled
     auto schedule = [&](bool pd) -> bool {
@@ -1785,25 +1913,28 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       double s = 0;
 #pragma unroll
       for (int u = 0; u < M; u++) s += Quh[u] * Quh[u];
-      gsum += sqrt(s);
+      gsum += (s > 0.0) ? s * rsqrt_nr(s) : 0.0;  // sqrt(s) without the IEEE sqrt sequence (2 ulp)
     }
     // gains: [K | k] = -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none
 #pragma unroll
     for (int u = 0; u < M; u++) Kh[u] = (j == 13) ? 0.0 : Quh[u];
     if (__any(use_lu)) {
-      double Kl[M], Ac[M][M];
+      // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics on the matrix itself (rare path:
+      // rebuild it -- the factorisation ran in place -- and replicate it to every lane)
+      double Kl[M], Ac[M][M], Qc[M];
+      build_quu(mu_used, Qc);
 #pragma unroll
       for (int u = 0; u < M; u++) {
         Kl[u] = Kh[u];
-#pragma unroll
-        for (int k = 0; k < M; k++) Ac[u][k] = (k <= u) ? Qrep[u][k] : Qrep[k][u];
+        Ac[u][0] = bcast<0>(Qc[u]); Ac[u][1] = bcast<1>(Qc[u]); Ac[u][2] = bcast<2>(Qc[u]); Ac[u][3] = bcast<3>(Qc[u]);
+        if constexpr (M > 4) { Ac[u][4] = bcast<4>(Qc[u]); Ac[u][5] = bcast<5>(Qc[u]); }
       }
       lu_solve<M>(Ac, Kl);
-      chol_solve<M>(Ls, dinv, Kh);
+      ldl_solve<M>(Uf, rinv, Kh);
 #pragma unroll
       for (int u = 0; u < M; u++) Kh[u] = use_lu ? Kl[u] : Kh[u];
     } else {
-      chol_solve<M>(Ls, dinv, Kh);
+      ldl_solve<M>(Uf, rinv, Kh);
     }
 #pragma unroll
     for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
