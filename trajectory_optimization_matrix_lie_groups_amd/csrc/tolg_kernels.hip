@@ -1565,7 +1565,7 @@ template <int M, int J = 0>
 TOLG_DEV bool ldl_factor(double (&a)[M], double (&rinv)[M], int jl, bool ok = true) {
   const double d = bcast<J>(a[J]);
   ok = ok && (d > 0.0);
-  rinv[J] = rcp_nr(ok ? d : 1.0);
+  rinv[J] = rcp_nr(d);  // a non-positive pivot leaves garbage behind it: the caller discards the factors when !ok
   if constexpr (J + 1 < M) {
     // multiplier of this lane's column: -Q[J][c] / d_J for the columns right of the pivot, 0 for the others (their
     // rows below J are already final factor entries and must not move)
@@ -1610,6 +1610,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   if (!__any(act)) return;
   const int N = P.N;
   __shared__ double TR[4][12 * 13];
+  __shared__ double TRZ[12];  // zeros: what the vector lanes "transpose-read" (see the symmetrisation below)
 
   // lane-dependent constants
   const double m12 = (j < 12) ? 1.0 : 0.0;                  // matrix columns
@@ -1639,8 +1640,14 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = C.Bt[k]; KC[j][KC_BB + k] = C.Bb[k]; }
     KC[j][KC_BD] = (j < M) ? fu_entry<M>(C, j < 6 ? j : 0, j) : 0.0;
   }
+  if (lane < 12) TRZ[lane] = 0.0;
   __builtin_amdgcn_wave_barrier();
   const double* KCj = KC[j];
+  // V <- (V + V^T) / 2 for the matrix columns, V <- V for the vector columns, without a per-entry select: a vector
+  // lane reads zeros for the transposed entry and scales by 1 instead of 1/2 (bitwise what the select gave)
+  const double* trd = (j < 12) ? &TR[g][j * 13] : TRZ;
+  const double hsym = (j < 12) ? 0.5 : 1.0;
+  const double kneg = (j == 13) ? 0.0 : -1.0;  // gains are -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none
   // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
   int fT = REC_D, fM = REC_D + 3;
   double mT = 0.0, mM = 0.0;
@@ -1915,9 +1922,9 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       for (int u = 0; u < M; u++) s += Quh[u] * Quh[u];
       gsum += (s > 0.0) ? s * rsqrt_nr(s) : 0.0;  // sqrt(s) without the IEEE sqrt sequence (2 ulp)
     }
-    // gains: [K | k] = -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none
+    // gains: [K | k] = -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none (kneg: -1, or 0 in that lane)
 #pragma unroll
-    for (int u = 0; u < M; u++) Kh[u] = (j == 13) ? 0.0 : Quh[u];
+    for (int u = 0; u < M; u++) Kh[u] = Quh[u];
     if (__any(use_lu)) {
       // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics on the matrix itself (rare path:
       // rebuild it -- the factorisation ran in place -- and replicate it to every lane)
@@ -1937,7 +1944,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
       ldl_solve<M>(Uf, rinv, Kh);
     }
 #pragma unroll
-    for (int u = 0; u < M; u++) Kh[u] = -Kh[u];
+    for (int u = 0; u < M; u++) Kh[u] = kneg * Kh[u];
 #pragma unroll
     for (int u = 0; u < M; u++) Kst[u] = Kh[u];
     STAMP(5)
@@ -1958,10 +1965,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 12; r++) {
-      double vt = (j < 12) ? TR[g][j * 13 + r] : Vn[r];
-      V[r] = 0.5 * (Vn[r] + vt);
-    }
+    for (int r = 0; r < 12; r++) V[r] = hsym * (Vn[r] + trd[r]);
     STAMP(6)
   };
 
