@@ -52,7 +52,7 @@ def _assert_same(keep, rs):
             assert _rel(a, b) <= _TOL[k], (k, _rel(a, b))
 
 
-@pytest.mark.parametrize("B,N", [(37, 45), (16, 8), (3, 3), (64, 130)])
+@pytest.mark.parametrize("B,N", [(37, 45), (16, 8), (3, 3), (64, 130), (5, 1), (20, 2)])
 def test_fused_equals_split_se3(B, N):
     """Ragged shapes: B not a multiple of the 16 trajectories of a workgroup (nor of 4), N not a multiple
     of the four knots of a helper pass, N below / above the 24-knot LDS ring (slot reuse)."""
@@ -107,3 +107,14 @@ def test_fused_with_al_terms():
         solver.set_al(None)
     assert _rel(res["auto"][0].cpu(), res["split"][0].cpu()) < 1e-9
     assert _rel(res["auto"][1].cpu(), res["split"][1].cpu()) < 1e-11
+
+
+def test_fused_so3_embedding():
+    """SO3Dynamics in the SE(3) containers (TOLG_DYN_SO3) through the fused launch."""
+    B, N, K = 7, 60, 6
+    prob, x0_q, x0_xi, us0 = workloads.so3_tracking(B, N=N)
+    keep, rs = _both(prob, x0_q, x0_xi, us0, K, tol_grad_norm=0.0, tol_d_norm=0.0)
+    _assert_same(keep, rs)
+    o = ob.fit_batch(_oracle_problem(prob), x0_q, x0_xi, us0, mode="ms", max_iter=K)
+    assert _rel(keep["J_hist"].cpu(), o["J_hist"]) < 1e-9
+    assert _rel(keep["us"].cpu(), o["us"]) < 1e-6
