@@ -282,9 +282,14 @@ TOLG_DEV DynK dynk_load(const CT& C) {
 // dyn_f with the pinned constants: the same expressions in the same order as the diagJ branch above,
 // in two halves.  The pose half needs the state only, so the rollout runs it while the gains it is
 // about to multiply are still in flight.
-TOLG_DEV Pose dyn_pose_k(const DynK& K, const State& S) {
-  Pose E = se3_exp_fast(K.dt * S.w, K.dt * S.v);
+TOLG_DEV Pose dyn_pose_k(const DynK& K, const State& S, SeriesGate g) {
+  Pose E = se3_exp_fast(K.dt * S.w, K.dt * S.v, g);
   return se3_project(se3_compose(S.X, E));
+}
+TOLG_DEV Pose dyn_pose_k(const DynK& K, const State& S) {
+  const V3 wd = K.dt * S.w;
+  const double th2 = dot(wd, wd);
+  return dyn_pose_k(K, S, series_gate(exp_small(th2), exp_dom(th2)));
 }
 template <int M, class CT, int PK>
 TOLG_DEV void dyn_twist_k(const DynK& K, const CT& C, const State& S, const double (&u)[M], State& F) {
@@ -454,32 +459,42 @@ TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
 // Exp / Log and the Jacobian coefficients use the series forms of tolg_lie.h inside their convergence domains.
 // lcost: where the stage cost goes instead of P.SC (the fused kernel sums the costs of its own trajectories itself,
 // from LDS; a CLOSED trajectory has no defect to sum either).
-template <int M, bool CLOSED = false, class CT, class NextFn>
+// TERM: -1 = decided per lane (i == N), 0 / 1 = the caller knows that no / every lane it calls with sits on the
+// terminal knot.  With a wave-uniform answer the weight matrices below are selected once per wave and read with
+// scalar loads; a per-lane select turns every one of their ~150 reads into a vector-memory load of one address.
+template <int M, bool CLOSED = false, int TERM = -1, class CT, class NextFn>
 TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const State& S, const double (&u)[M],
                        NextFn next_state, double* lcost = nullptr) {
-  const bool term = (i == P.N);
+  const bool term = TERM < 0 ? (i == P.N) : (TERM == 1);
   const double dt = C.dt;
+  // One gate for all the series evaluations of the knot: the tracking error (Log, then V^-1 and Q at its angle,
+  // which the Log bounds cover) and the step rotation (V, Q, Exp at dt w).
+  const V3 wd = dt * S.w, vd = dt * S.v;
+  const double* r = P.ref + 13 * (size_t)i;
+  Pose Xr;
+  Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
+  Xr.t = v3(r[4], r[5], r[6]);
+  const Pose De = se3_compose(S.X, se3_inverse(Xr));
+  const double ye = quat_vec2(De.q), th2d = dot(wd, wd);
+  const SeriesGate sg = series_gate(log_small(ye) && coef_small(th2d), log_dom(ye) && exp_dom(th2d));
   // ---------------- cost: e = Log(X Xref^-1), J_e = Jr^-1(e) Ad(Xref)  (traopt_cost.py:659-839)
   {
-    const double* r = P.ref + 13 * (size_t)i;
-    Pose Xr;
-    Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
-    Xr.t = v3(r[4], r[5], r[6]);
     V3 ew, ev;
-    se3_log_fast(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+    se3_log_fast(De, ew, ev, sg);
     // weights: l_xx switches to P at the terminal knot; l and l_x too, except for the SO3 cost which
     // keeps Q there (traopt_cost.py:434-438, :480-483 vs :530-531)
     const bool so3 = so3_family(C.kind);
-    const double* W1 = term ? C.P1 : C.W1;
-    const double* W2 = term ? C.P2 : C.W2;
-    const double* G1 = (term && !so3) ? C.P1 : C.W1;
-    const double* G2 = (term && !so3) ? C.P2 : C.W2;
+    // (pointers into C keep its address space: scalar loads when C is the constant-space view and term is uniform)
+    const auto W1 = term ? &C.P1[0] : &C.W1[0];
+    const auto W2 = term ? &C.P2[0] : &C.W2[0];
+    const auto G1 = (term && !so3) ? &C.P1[0] : &C.W1[0];
+    const auto G2 = (term && !so3) ? &C.P2[0] : &C.W2[0];
     double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
     double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
     double th2 = dot(ew, ew);
     double Ji[9], Qr[9], T1[9], Bm[9], Rr[9], Tr[9], Ja[9], Jb[9];
-    ljacinv33(neg(ew), ljacinv_coef_fast(th2), Ji);  // Jr^-1(w) = Jl^-1(-w)
-    Q33(neg(ev), neg(ew), so3_coef_fast(th2, true), Qr);
+    ljacinv33(neg(ew), ljacinv_coef_fast(th2, sg), Ji);  // Jr^-1(w) = Jl^-1(-w)
+    Q33(neg(ev), neg(ew), so3_coef_fast(th2, true, sg), Qr);
     mul33(Ji, Qr, T1);
     mul33(T1, Ji, Bm);  // rjacinv lower-left block = -Bm
     q_to_R(Xr.q, Rr);
@@ -587,10 +602,9 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
   }
   if (term) return;
   // ---------------- dynamics Jacobian blocks (traopt_dynamics.py:802-837, :1416-1469)
-  V3 wd = dt * S.w, vd = dt * S.v;
-  SO3Coef kc = so3_coef_fast(dot(wd, wd), true);
+  SO3Coef kc = so3_coef_fast(dot(wd, wd), true, sg);
   Pose E;
-  E.q = so3_exp_fast(wd);
+  E.q = so3_exp_fast(wd, sg);
   E.t = ljac_apply(wd, kc, vd);
   {
     // Ad(Exp(tau))^-1 = Ad(E^-1) = [[Ri,0],[[ti]x Ri, Ri]]
@@ -2109,15 +2123,20 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   __builtin_amdgcn_sched_barrier(0);
   RSTAMP(1)
   // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
+  // one gate for the two series evaluations of the step (Log here, Exp in the pose half of the dynamics)
   V3 ew, ev;
-  se3_log_fast(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+  const Pose Dx = se3_compose(se3_inverse(So.X), Sn.X);
+  const V3 wdt = DK.dt * Sn.w;
+  const double yl = quat_vec2(Dx.q), th2e = dot(wdt, wdt);
+  const SeriesGate sg = series_gate(log_small(yl) && exp_small(th2e), log_dom(yl) && exp_dom(th2e));
+  se3_log_fast(Dx, ew, ev, sg);
   double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
                   Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
   // du = alpha k + K dx: this lane's two rows, then quad broadcast (identical bits in all four lanes)
   // the pose half of f(x^, u^) does not depend on u^: it runs here, ahead of the gain product, and gives
   // the gain loads issued at the top of the step another ~700 cycles to land
   State Fn;
-  if (!LINEAR && DK.diag) Fn.X = dyn_pose_k(DK, Sn);
+  if (!LINEAR && DK.diag) Fn.X = dyn_pose_k(DK, Sn, sg);
   RSTAMP(2)
   double mine[2];
 #pragma unroll
@@ -2534,7 +2553,9 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
         for (int a = 0; a < M; a++) P.cur_u[UIDX(a, i, b)] = u[a];
       }
       if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
-      lin_knot<M, true>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
+      // the terminal knot (in the last group only) goes separately: see lin_knot's TERM
+      if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
+      if (4 * g + 3 >= N && i == N) lin_knot<M, true, 1>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
     }
     done++;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every ring read of this pass has returned

@@ -196,46 +196,113 @@ TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
   v = ljacinv_apply(w, cl, X.t);
 }
 // ------------------------------------------------------------------------------------------------
-// Series fast paths for the sequential rollout (K3), where Exp and Log sit on the critical path of a
-// wave that has nothing else to run.  Inside their domains they need no sqrt, no sincos / atan2 and no
-// division; truncation errors are below 1e-17 relative, i.e. they agree with the closed forms above
-// to rounding.  Outside (a rotation of more than 1 rad per step, a deviation of more than ~29 degrees)
-// they fall back to the closed forms; manif's small-angle branches (th2 <= 1e-10) are kept as they are.
+// Series fast paths for the sequential rollout (K3) and the linearisation, where Exp and Log sit on the critical
+// path of a wave that has nothing else to run.  Inside their domains they need no sqrt, no sincos / atan2 and no
+// division; truncation errors are below 1e-17 relative, i.e. they agree with the closed forms above to rounding.
+// Shape of every function: the series runs unconditionally as straight-line code, manif's small-angle values
+// (th2 <= 1e-10) are selected in, and the lanes outside the domain (a rotation of more than 1 rad per step, a
+// deviation of more than ~29 degrees) are redone with the closed form behind a wave-uniform branch that a
+// tracking solve never takes after its first iterations.  The series have two lengths: where the argument is
+// `small` (per-step rotation below 0.2 rad, deviation below 0.06 rad -- the steady state of a tracking solve) the
+// terms past the short length are below 1e-17 of the sum, and a wave whose lanes are all small skips them.
+// Every VALUE is decided per lane from the lane's own argument: a trajectory's result does not depend on its
+// neighbours in the wave.  The two wave-uniform facts -- does any lane need the long tier / the closed form --
+// come in a SeriesGate, which a caller with several evaluations in a row computes once for all of them (a
+// vector-compare -> scalar-branch round trip costs ~17 cycles on a chain that has nothing to hide it behind).
 // ------------------------------------------------------------------------------------------------
+TOLG_DEV bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+struct SeriesGate { bool any_long, any_fb; };
+TOLG_DEV SeriesGate series_gate(bool small, bool dom) {
+  SeriesGate g;
+  g.any_long = any_lane(!small);
+  g.any_fb = any_lane(!dom);
+  return g;
+}
+// Per-lane predicates of the four argument kinds.  A gate built from log_small / log_dom of y = |q_v|^2 also
+// covers the evaluations at the resulting angle th2 = (2 asin sqrt y)^2: y < 1e-3 gives th2 < 4.002e-3 (inside
+// coef_small and ljinv_small), y < 1/16 gives th2 < 0.2554 (inside coef_dom and ljinv_dom).
+TOLG_DEV bool exp_small(double th2) { return th2 < 0.04; }                   // 5 / 6 / 6 terms reach 1e-17
+TOLG_DEV bool exp_dom(double th2) { return th2 > TOLG_EPS && th2 < 1.0; }
+TOLG_DEV bool log_small(double y) { return y < 1e-3; }                       // 6 / 5 terms
+TOLG_DEV bool log_dom(double y) { return y < 0.0625; }
+TOLG_DEV bool coef_small(double th2) { return th2 < 0.04; }                  // 6 terms of each
+TOLG_DEV bool coef_dom(double th2) { return th2 < 1.0; }
+TOLG_DEV bool ljinv_small(double th2) { return th2 < 0.01; }                 // 5 terms
+TOLG_DEV bool ljinv_dom(double th2) { return th2 < 0.26; }
+// r y + c as one three-address instruction.  Left to itself the compiler turns a Horner step whose coefficient
+// lives in a register across the knot loop into v_mov_b64 + v_fmac_f64 (the two-address form clobbers its addend),
+// i.e. two issue slots of a wave that is issue-bound at one fp64 instruction per ~5 cycles.
+TOLG_DEV double horner_step(double r, double y, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(r), "v"(y), "v"(c));
+  return d;
+}
 // sum_k c[k] y^k, Horner
 template <int N>
 TOLG_DEV double horner(const double (&c)[N], double y) {
   double r = c[N - 1];
 #pragma unroll
-  for (int k = N - 2; k >= 0; k--) r = fma(r, y, c[k]);
+  for (int k = N - 2; k >= 0; k--) r = horner_step(r, y, c[k]);
   return r;
 }
-TOLG_DEV Pose se3_exp_fast(V3 w, V3 v) {
-  const double th2 = dot(w, w);
-  if (!(th2 > TOLG_EPS && th2 < 1.0)) return se3_exp(w, v);
-  // x = th/2, y = x^2:  sin(x)/x, cos(x), and (th - sin th)/th^3 as series in y resp. th2
+// Two-tier Horner: lanes with `small` take the low NS coefficients only.  any_long (wave-uniform) false promises
+// that every lane is small.  The empty volatile asm keeps the compiler from speculating the upper part back into
+// the straight-line code.
+template <int NS, int N>
+TOLG_DEV double horner2(const double (&c)[N], double y, bool small, bool any_long) {
+  static_assert(NS >= 1 && NS <= N, "tier");
+  double r = c[NS - 1];
+  if (__builtin_expect(any_long, 0)) {
+    asm volatile("");
+    double rl = c[N - 1];
+#pragma unroll
+    for (int k = N - 2; k >= NS - 1; k--) rl = horner_step(rl, y, c[k]);
+    r = small ? r : rl;
+  }
+#pragma unroll
+  for (int k = NS - 2; k >= 0; k--) r = horner_step(r, y, c[k]);
+  return r;
+}
+// half-angle series shared by the two Exp: sin(x)/x and cos(x) in y = x^2 = th2/4
+TOLG_DEV void half_angle_series(double th2, bool sm, bool any_long, double& so, double& cw) {
   const double S[9] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
                        -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
   const double Cc[9] = {1.0, -1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600,
                         -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+  const double y = 0.25 * th2;
+  so = 0.5 * horner2<5>(S, y, sm, any_long);   // sin(th/2)/th
+  cw = horner2<6>(Cc, y, sm, any_long);        // cos(th/2)
+}
+TOLG_DEV Pose se3_exp_fast(V3 w, V3 v, SeriesGate g) {
+  const double th2 = dot(w, w);
+  const bool sm = exp_small(th2);
   const double Bc[10] = {1.0 / 6, -1.0 / 120, 1.0 / 5040, -1.0 / 362880, 1.0 / 39916800, -1.0 / 6227020800.0,
                          1.0 / 1307674368000.0, -1.0 / 355687428096000.0, 1.0 / 121645100408832000.0,
                          -1.0 / 51090942171709440000.0};
-  const double y = 0.25 * th2;
-  const double so = 0.5 * horner(S, y);  // sin(th/2)/th
+  double so, cw;
+  half_angle_series(th2, sm, g.any_long, so, cw);
   Pose X;
-  X.q.x = so * w.x; X.q.y = so * w.y; X.q.z = so * w.z; X.q.w = horner(Cc, y);
+  X.q.x = so * w.x; X.q.y = so * w.y; X.q.z = so * w.z; X.q.w = cw;
   SO3Coef k;
-  k.a = 2.0 * so * so;                    // (1 - cos th)/th^2 = 2 sin^2(th/2)/th^2
-  k.b = horner(Bc, th2);                  // (th - sin th)/th^3
+  k.a = 2.0 * so * so;                          // (1 - cos th)/th^2 = 2 sin^2(th/2)/th^2
+  k.b = horner2<6>(Bc, th2, sm, g.any_long);    // (th - sin th)/th^3
   k.c1 = k.c2 = k.c3 = 0;
   X.t = ljac_apply(w, k, v);
+  if (__builtin_expect(g.any_fb, 0)) {
+    asm volatile("");
+    if (!exp_dom(th2)) X = se3_exp(w, v);
+  }
   return X;
 }
-TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
+TOLG_DEV Pose se3_exp_fast(V3 w, V3 v) {
+  const double th2 = dot(w, w);
+  return se3_exp_fast(w, v, series_gate(exp_small(th2), exp_dom(th2)));
+}
+TOLG_DEV double quat_vec2(Q4 q) { return q.x * q.x + q.y * q.y + q.z * q.z; }  // sin^2 of the half angle
+TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v, SeriesGate g) {
   const Q4 q = X.q;
-  const double y = q.x * q.x + q.y * q.y + q.z * q.z;  // sin^2 of the half angle
-  if (!(y > TOLG_EPS && y < 0.0625)) { se3_log(X, w, v); return; }
+  const double y = quat_vec2(q);
+  const bool tiny = !(y > TOLG_EPS), sm = log_small(y);
   // asin(sqrt y)/sqrt y and 1/t^2 - cot(t/2)/(2t) = sum |B_{2k+2}|/(2k+2)! t^2k
   const double A[14] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144, 0.030381944444444444,
                         0.022372159090909092, 0.017352764423076924, 0.01396484375, 0.011551800896139705,
@@ -244,21 +311,31 @@ TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
   const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
                        2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
                        8.586062056277845e-15};
-  double c = 2.0 * horner(A, y);        // angle / |q_v|
-  const double t2 = c * c * y;          // angle^2
-  double cl = horner(L, t2);
-  if (t2 <= TOLG_EPS) cl = 0.0;         // manif's small-angle V^-1 = I - W/2
-  if (q.w < 0.0) c = -c;                // q and -q are the same rotation: take the w > 0 representative
+  double c = 2.0 * horner2<6>(A, y, sm, g.any_long);  // angle / |q_v|
+  const double t2 = c * c * y;                        // angle^2 (< 4.1e-3 when sm)
+  double cl = horner2<5>(L, t2, sm, g.any_long);
+  if (tiny) c = 2.0;                      // manif's small-angle Log: 2 q_v
+  if (tiny || t2 <= TOLG_EPS) cl = 0.0;   // and its small-angle V^-1 = I - W/2
+  if (q.w < 0.0) c = -c;                  // q and -q are the same rotation: take the w > 0 representative
   w = v3(c * q.x, c * q.y, c * q.z);
   v = ljacinv_apply(w, cl, X.t);
+  if (__builtin_expect(g.any_fb, 0)) {
+    asm volatile("");
+    if (!log_dom(y)) se3_log(X, w, v);
+  }
+}
+TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
+  const double y = quat_vec2(X.q);
+  se3_log_fast(X, w, v, series_gate(log_small(y), log_dom(y)));
 }
 // Coefficients of V(w) and of the SE(3) Q block as series in th^2 (th^2 < 1: one time step of rotation, or a
 // tracking error below one radian; otherwise the closed forms).  (1 - cos t)/t^2 = sum (-1)^k t^2k/(2k+2)!,
 // (t - sin t)/t^3 = sum (-1)^k t^2k/(2k+3)!, (t^2 + 2 cos t - 2)/(2 t^4) = sum (-1)^k t^2k/(2k+4)!,
 // (2t - 3 sin t + t cos t)/(2 t^5) = sum (-1)^k (k+1) t^2k/(2k+5)!.  No sqrt / sincos / division, and none of the
-// cancellation the closed forms suffer for small angles.
-TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
-  if (!(th2 > TOLG_EPS && th2 < 1.0)) return so3_coef(th2, want_q);
+// cancellation the closed forms suffer for small angles.  For th^2 <= 1e-10 a, b, c1 take so3_coef's constants;
+// its two-term c2 and c3 are what the series rounds to there.
+TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q, SeriesGate g) {
+  const bool tiny = !(th2 > TOLG_EPS), sm = coef_small(th2);
   const double A[10] = {0.5, -0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05, 2.755731922398589e-07,
                         -2.08767569878681e-09, 1.1470745597729725e-11, -4.779477332387385e-14, 1.5619206968586225e-16,
                         -4.110317623312165e-19};
@@ -266,8 +343,9 @@ TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
                         2.505210838544172e-08, -1.6059043836821613e-10, 7.647163731819816e-13, -2.8114572543455206e-15,
                         8.22063524662433e-18, -1.9572941063391263e-20};
   SO3Coef k;
-  k.a = horner(A, th2);
-  k.b = horner(B, th2);
+  const double a = horner2<6>(A, th2, sm, g.any_long), b = horner2<6>(B, th2, sm, g.any_long);
+  k.a = tiny ? 0.5 : a;
+  k.b = tiny ? 0.0 : b;
   if (want_q) {
     const double C2[9] = {0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07,
                           2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16,
@@ -275,34 +353,53 @@ TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
     const double C3[9] = {0.008333333333333333, -0.0003968253968253968, 8.267195767195768e-06, -1.0020843354176688e-07,
                           8.029521918410807e-10, -4.58829823909189e-12, 1.9680200780418645e-14, -6.576508197299464e-17,
                           1.7615646957052136e-19};
-    k.c1 = k.b;
-    k.c2 = horner(C2, th2);
-    k.c3 = horner(C3, th2);
+    k.c1 = b;
+    k.c2 = horner2<6>(C2, th2, sm, g.any_long);
+    k.c3 = horner2<6>(C3, th2, sm, g.any_long);
   } else {
     k.c1 = k.c2 = k.c3 = 0;
   }
+  if (__builtin_expect(g.any_fb, 0)) {
+    asm volatile("");
+    if (!coef_dom(th2)) k = so3_coef(th2, want_q);
+  }
   return k;
 }
-// coefficient of W^2 in V(w)^-1 (ljacinv_coef) as the series of se3_log_fast, th^2 < 1/4
-TOLG_DEV double ljacinv_coef_fast(double th2) {
-  if (!(th2 > TOLG_EPS && th2 < 0.25)) return ljacinv_coef(th2);
+TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
+  return so3_coef_fast(th2, want_q, series_gate(coef_small(th2), coef_dom(th2)));
+}
+// coefficient of W^2 in V(w)^-1 (ljacinv_coef) as the series of se3_log_fast
+TOLG_DEV double ljacinv_coef_fast(double th2, SeriesGate g) {
   const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
                        2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
                        8.586062056277845e-15};
-  return horner(L, th2);
+  double r = horner2<5>(L, th2, ljinv_small(th2), g.any_long);
+  if (!(th2 > TOLG_EPS)) r = 0.0;
+  if (__builtin_expect(g.any_fb, 0)) {
+    asm volatile("");
+    if (!ljinv_dom(th2)) r = ljacinv_coef(th2);
+  }
+  return r;
+}
+TOLG_DEV double ljacinv_coef_fast(double th2) {
+  return ljacinv_coef_fast(th2, series_gate(ljinv_small(th2), ljinv_dom(th2)));
 }
 // so3_exp with the half-angle series of se3_exp_fast
+TOLG_DEV Q4 so3_exp_fast(V3 w, SeriesGate g) {
+  const double th2 = dot(w, w);
+  double so, cw;
+  half_angle_series(th2, exp_small(th2), g.any_long, so, cw);
+  Q4 q;
+  q.x = so * w.x; q.y = so * w.y; q.z = so * w.z; q.w = cw;
+  if (__builtin_expect(g.any_fb, 0)) {
+    asm volatile("");
+    if (!exp_dom(th2)) q = so3_exp(w);
+  }
+  return q;
+}
 TOLG_DEV Q4 so3_exp_fast(V3 w) {
   const double th2 = dot(w, w);
-  if (!(th2 > TOLG_EPS && th2 < 1.0)) return so3_exp(w);
-  const double S[9] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
-                       -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
-  const double Cc[9] = {1.0, -1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600,
-                        -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
-  const double y = 0.25 * th2, so = 0.5 * horner(S, y);
-  Q4 q;
-  q.x = so * w.x; q.y = so * w.y; q.z = so * w.z; q.w = horner(Cc, y);
-  return q;
+  return so3_exp_fast(w, series_gate(exp_small(th2), exp_dom(th2)));
 }
 TOLG_DEV Pose se3_compose(Pose A, Pose B) {
   Pose C;
