@@ -720,8 +720,10 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
   double d2 = 0;
 #pragma unroll
   for (int a = 0; a < 12; a++) d2 += d[a] * d[a];
-  rec_run<REC_D, 12>(P, i, b, d);
-  if (!(CLOSED && lcost)) P.SD[(size_t)i * P.Bp + b] = d2;
+  if (!(CLOSED && lcost)) {  // the fused launch neither stores nor sums a defect that is zero by construction
+    rec_run<REC_D, 12>(P, i, b, d);
+    P.SD[(size_t)i * P.Bp + b] = d2;
+  }
 }
 
 template <int M>
@@ -1616,7 +1618,11 @@ TOLG_DEV void ldl_solve(const double (&a)[M], const double (&rinv)[M], double (&
 // DIAGJ: I_b and J_v are diagonal (every reference script): F_u's two 3x3 blocks are diagonal (the drone's
 // J_v^-1 e_z column has one entry), so each input touches one row of (V + mu I) F_x instead of three.
 template <int M, bool VARB = false, bool GRAV = true, bool DIAGJ = false>
-__global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
+__global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
+  // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
+  // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here
+  const int ms = flags & 1;
+  const bool closed = (flags & 2) != 0;
   const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
@@ -1669,7 +1675,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   else if (j < 6) { fM = REC_RI + 3 * (j - 3); mM = 1; }
   else if (j < 9) { fT = REC_JR + 3 * (j - 6); fM = REC_QR + 3 * (j - 6); mT = 1; mM = 1; }
   else if (j < 12) { fM = REC_JR + 3 * (j - 9); mM = 1; }
-  else if (j == 12) { mT = 1; mM = 1; }
+  else if (j == 12 && !closed) { mT = 1; mM = 1; }
   int fL[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) fL[r] = (j < 6) ? REC_LXX + sym6(r, j) : REC_LX + r;
@@ -1685,7 +1691,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int ms) {
   unsigned oT[3], oM[3];  // fT / fM are odd for every second lane: per-row offsets instead of base + r
 #pragma unroll
   for (int r = 0; r < 3; r++) { oT[r] = (mT != 0.0) ? vr + FOFF(fT + r) : OOB; oM[r] = (mM != 0.0) ? vr + FOFF(fM + r) : OOB; }
-  const bool hasB = (j >= 6 && j < 12) || j == 12, isVec = (j == 12 || j == 13);
+  const bool hasB = (j >= 6 && j < 12) || (j == 12 && !closed), isVec = (j == 12 || j == 13);
   const unsigned vBt = hasB ? vr + FOFF(fB) : OOB;  // fB is even (REC_A22, REC_D even): rows r, r+1 are one 16-byte pair
   const unsigned vVec = isVec ? vr : OOB;           // fields only the vector columns read (l_x[6:12], l_u)
   const unsigned vG = GK_VG(b, M) + GOFF(0, (j < 13 ? j : 12), M);
@@ -2205,6 +2211,53 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   return Nx;
 }
 
+// The fused rollout's step (accept-always, alpha = 1): the twist half of roll_step.  The pose half of the dynamics,
+// X_{i+1} = project(X_i Exp(xi_i dt)), depends on the state alone; a second wavefront runs that chain one step ahead
+// (k_rollout_lin) and get_pose() hands over X_i.  Sn holds xi_i on entry (its pose is filled in here) and xi_{i+1}
+// on return.  Same expressions in the same order as roll_step.
+template <int M, class CT, class LoadFn, class PoseFn>
+TOLG_DEV void roll_step_twist(const CT& C, const DynK& DK, const State& So, State& Sn, double (&un_out)[M],
+                              LoadFn load_in, PoseFn get_pose RST_PARAM) {
+  RSTAMP(0)
+  RollIn<M> R;
+  load_in(R);  // in flight while Log runs
+  __builtin_amdgcn_sched_barrier(0);
+  RSTAMP(1)
+  Sn.X = get_pose();
+  RSTAMP(5)
+  // state deviation [Log(q^-1 q_new); xi_new - xi]   (traopt_controller.py:2680-2687)
+  V3 ew, ev;
+  const Pose Dx = se3_compose(se3_inverse(So.X), Sn.X);
+  const double yl = quat_vec2(Dx.q);
+  se3_log_fast(Dx, ew, ev, series_gate(log_small(yl), log_dom(yl)));
+  const double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                        Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+  RSTAMP(2)
+  double mine[2];
+#pragma unroll
+  for (int sidx = 0; sidx < 2; sidx++) {
+    double sacc = R.G[sidx][12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) sacc += R.G[sidx][k] * e[k];
+    mine[sidx] = sacc;
+  }
+  double un[M], du[M];
+  du[0] = quad_bcast<0>(mine[0]); du[1] = quad_bcast<0>(mine[1]);
+  du[2] = quad_bcast<1>(mine[0]); du[3] = quad_bcast<1>(mine[1]);
+  if constexpr (M == 6) { du[4] = quad_bcast<2>(mine[0]); du[5] = quad_bcast<2>(mine[1]); }
+#pragma unroll
+  for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
+  RSTAMP(3)
+  State Fn;
+  if (DK.diag) dyn_twist_k<M, CT, 0>(DK, C, Sn, un, Fn);
+  else Fn = dyn_f<M, CT, 0>(C, Sn, un);
+  RSTAMP(4)
+  Sn.w = Fn.w;
+  Sn.v = Fn.v;
+#pragma unroll
+  for (int a = 0; a < M; a++) un_out[a] = un[a];
+}
+
 template <int M, bool LINEAR, bool ALPHA1, int PK = 0>
 __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
@@ -2292,21 +2345,39 @@ TOLG_DEV bool rl_wait_ge(rl_sync_t p, int v) {
   }
   return false;
 }
-// state ring slot: [pair][trajectory][2] doubles, state fields 0..12 (+ padding) in pairs 0..6, controls in 7..9
-TOLG_DEV void rl_put_state(double* slot, int tt, const State& S) {
+// state ring slot: [pair][trajectory][2] doubles: the pose in pairs 0..3 (quaternion, translation, padding), the
+// twist in pairs 4..6, the controls in 7..9.  Pose and twist of a knot come from different wavefronts.
+TOLG_DEV void rl_put_pose(double* slot, int tt, const Pose& X) {
   f64x2* p = reinterpret_cast<f64x2*>(slot) + tt;
-  p[0 * 16] = f64x2{S.X.q.x, S.X.q.y}; p[1 * 16] = f64x2{S.X.q.z, S.X.q.w}; p[2 * 16] = f64x2{S.X.t.x, S.X.t.y};
-  p[3 * 16] = f64x2{S.X.t.z, S.w.x};   p[4 * 16] = f64x2{S.w.y, S.w.z};     p[5 * 16] = f64x2{S.v.x, S.v.y};
-  p[6 * 16] = f64x2{S.v.z, 0.0};
+  p[0 * 16] = f64x2{X.q.x, X.q.y}; p[1 * 16] = f64x2{X.q.z, X.q.w}; p[2 * 16] = f64x2{X.t.x, X.t.y};
+  p[3 * 16] = f64x2{X.t.z, 0.0};
+}
+TOLG_DEV void rl_put_twist(double* slot, int tt, V3 w, V3 v) {
+  f64x2* p = reinterpret_cast<f64x2*>(slot) + tt;
+  p[4 * 16] = f64x2{w.x, w.y}; p[5 * 16] = f64x2{w.z, v.x}; p[6 * 16] = f64x2{v.y, v.z};
+}
+TOLG_DEV Pose rl_get_pose(const double* slot, int tt) {
+  const f64x2* p = reinterpret_cast<const f64x2*>(slot) + tt;
+  const f64x2 a = p[0 * 16], b = p[1 * 16], c = p[2 * 16], d = p[3 * 16];
+  Pose X;
+  X.q.x = a.x; X.q.y = a.y; X.q.z = b.x; X.q.w = b.y;
+  X.t = v3(c.x, c.y, d.x);
+  return X;
+}
+TOLG_DEV void rl_get_twist(const double* slot, int tt, V3& w, V3& v) {
+  const f64x2* p = reinterpret_cast<const f64x2*>(slot) + tt;
+  const f64x2 e = p[4 * 16], f = p[5 * 16], g = p[6 * 16];
+  w = v3(e.x, e.y, f.x);
+  v = v3(f.y, g.x, g.y);
+}
+TOLG_DEV void rl_put_state(double* slot, int tt, const State& S) {
+  rl_put_pose(slot, tt, S.X);
+  rl_put_twist(slot, tt, S.w, S.v);
 }
 TOLG_DEV State rl_get_state(const double* slot, int tt) {
-  const f64x2* p = reinterpret_cast<const f64x2*>(slot) + tt;
-  const f64x2 a = p[0 * 16], b = p[1 * 16], c = p[2 * 16], d = p[3 * 16], e = p[4 * 16], f = p[5 * 16], g = p[6 * 16];
   State S;
-  S.X.q.x = a.x; S.X.q.y = a.y; S.X.q.z = b.x; S.X.q.w = b.y;
-  S.X.t = v3(c.x, c.y, d.x);
-  S.w = v3(d.y, e.x, e.y);
-  S.v = v3(f.x, f.y, g.x);
+  S.X = rl_get_pose(slot, tt);
+  rl_get_twist(slot, tt, S.w, S.v);
   return S;
 }
 // input ring slot (bytes): the gains of the workgroup's four 4-trajectory groups exactly as they lie in GK
@@ -2406,22 +2477,32 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     for (int k = 0; k < 8; k++) ST.acc[k] = 0;
     ST.t = __builtin_amdgcn_s_memtime();
 #endif
-    auto finish_step = [&](int i) {  // publish u^_i, x^_{i+1}
+    // The pose of x^_i comes from the pose wavefront (sync[7] = poses published).  It is read speculatively
+    // right after this wave's own publish of step i - 1 -- counter first, then the data: LDS operations execute in
+    // order, so a counter value >= i vouches for the data read behind it -- and only re-read after a poll if the
+    // pose wave was late (it has a whole step of slack).
+    int pose_seen = 0;
+    Pose Xspec = Sn.X;
+    auto finish_step = [&](int i) {  // publish u^_i and the twist of x^_{i+1}
       if (writer) {
         f64x2* pu = reinterpret_cast<f64x2*>(ring[i % RL_RING]) + 7 * 16 + tt;
 #pragma unroll
         for (int a = 0; a < M; a += 2) pu[(a / 2) * 16] = f64x2{un[a], un[a + 1]};
-        rl_put_state(ring[(i + 1) % RL_RING], tt, Sn);
+        rl_put_twist(ring[(i + 1) % RL_RING], tt, Sn.w, Sn.v);
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) vs[0] = i + 1;
+      pose_seen = vs[7];
+      asm volatile("" ::: "memory");
+      Xspec = rl_get_pose(ring[(i + 1) % RL_RING], tt);
     };
     // State-ring back-pressure, checked once per eight steps for the eight slots ahead (a poll is an LDS round
     // trip on the critical chain): steps i .. i+7 overwrite the slots of knots up to `old` = i + 8 - RL_RING, which
     // is safe once every group of four knots up to the one holding `old` has been linearised (a group also
     // reads the first state of the next group).  Helper h owns groups h, h + RL_NH, ...: it must have finished
-    // (old/4 - h) / RL_NH + 1 of them.
+    // (old/4 - h) / RL_NH + 1 of them.  (The pose wave writes slot i + 1 only after it has seen step i - 1
+    // published, which this check precedes.)
     auto slot_free = [&](int i) -> bool {
 #ifdef TOLG_EXP_NOLIN
       return true;
@@ -2433,26 +2514,43 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
         if (go >= h && !rl_wait_ge(vs + 2 + h, (go - h) / RL_NH + 1)) return false;
       return true;
     };
-    // one step: the nominal state of the NEXT knot is read from the input ring at the top of the step (one
-    // knot ahead, as the HBM version prefetched it), this knot's gains / controls inside roll_step
-    auto step = [&](int i, const State& So, State& Snext) -> bool {
+    // what step i needs before it starts: ring slots to publish into, its inputs, and the nominal state of knot
+    // i + 1 (read one knot ahead, as the HBM version prefetched it)
+    auto ahead = [&](int i, State& Snext) -> bool {
       if (!slot_free(i)) return false;
       if (i + 1 < N) {
         if (!need_inputs(i + 2)) return false;
         Snext = rl_in_state<M>(inring[(i + 1) % RL_DEPTH], tt);
       }
+      return true;
+    };
+    // one step.  So holds the nominal state of knot i on entry and of knot i + 2 on return: the look-ahead for
+    // step i + 1 runs BEFORE this step's publish, so that its counter reads do not wait behind the LDS writes of
+    // the publish (LDS operations of a wave return in order).
+    auto step = [&](int i, State& So) -> bool {
       __builtin_amdgcn_sched_barrier(0);
       const char* slot = inring[i % RL_DEPTH];
-      Sn = roll_step<M, false, true, 0, false>(P, C, DK, i, b, q, writer, vb, sB, 1.0, So, Sn, un,
-                                               [&](RollIn<M>& R) { rl_in_load<M>(slot, tt, q, R); } RST_ARG);
+      bool got = true;
+      roll_step_twist<M>(C, DK, So, Sn, un, [&](RollIn<M>& R) { rl_in_load<M>(slot, tt, q, R); },
+                         [&]() -> Pose {
+                           if (pose_seen < i) {
+                             got = rl_wait_ge(vs + 7, i);
+                             asm volatile("" ::: "memory");
+                             Xspec = rl_get_pose(ring[i % RL_RING], tt);
+                           }
+                           return Xspec;
+                         } RST_ARG);
+      if (!got) return false;
+      if (i + 1 < N && !ahead(i + 1, So)) return false;
       finish_step(i);
       RSTAMP(7)
       return true;
     };
-    for (int i = 0; i < N; i += 2) {
-      if (!(ok = step(i, Sa, Sb))) break;
+    ok = ahead(0, Sb);
+    for (int i = 0; ok && i < N; i += 2) {
+      if (!(ok = step(i, Sa))) break;
       if (i + 1 >= N) break;
-      if (!(ok = step(i + 1, Sb, Sa))) break;
+      if (!(ok = step(i + 1, Sb))) break;
     }
 #ifdef TOLG_STAMPS
     if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
@@ -2467,7 +2565,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     const int ntraj = (P.Bp - b0 < 16) ? P.Bp - b0 : 16;              // Bp is a multiple of 4
     const int gchunks = (ntraj / 4) * (IN::GSZ / 16);                 // 16-byte pieces of gains this workgroup owns
     auto issue = [&](int k) {
-      const unsigned dst = lds0 + (unsigned)(k % RL_DEPTH) * IN::SLOT;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(k % RL_DEPTH) * IN::SLOT));
       const char* gk = reinterpret_cast<const char*>(P.GK + gStride * k + (size_t)(b0 >> 2) * 13 * M * 4);
 #pragma unroll
       for (int c = 0; c < (IN::GAINS + 1023) / 1024; c++) {
@@ -2486,32 +2584,60 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
       const char* us = reinterpret_cast<const char*>(P.cur_u + uStride * k + b0);
       if (lane < M * 8) rl_dma16(us + (size_t)(lane >> 3) * sB + (lane & 7) * 16, dst + IN::GAINS + IN::STATE);
     };
-    // Keep the ring as full as the rollout allows (knot k may be issued once step k - RL_DEPTH has completed) and
-    // publish every knot as soon as it has landed: the memory queue retires in order, so "at most n knots still
-    // outstanding" is a counted s_waitcnt with an immediate.
-    static_assert((RL_DEPTH - 1) * IN::NDMA <= 63, "vmcnt is a 6-bit counter");
-    int issued = 0, published = 0, idle = 0;
-    while (published < N) {
-      const int prod = vs[0];
-      bool did = false;
-      while (issued < N && (issued < RL_DEPTH || prod >= issued - RL_DEPTH + 1)) { issue(issued); issued++; did = true; }
-      if (published < issued) {
-        switch (issued - published - 1) {
-          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * IN::NDMA) : "memory"); break;
-          case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IN::NDMA) : "memory"); break;
-          case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * IN::NDMA) : "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * IN::NDMA) : "memory"); break;
-        }
-        published++;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) vs[1] = published;
-        idle = 0;
-      } else if (!did) {
-        if (++idle > RL_POLLS) return;  // wave 0 reports the failure
-        __builtin_amdgcn_s_sleep(4);
+    // Inputs: knot k may be issued once step k - RL_DEPTH has completed; a knot is published once its DMAs have
+    // retired -- the memory queue retires in order, so "at most n knots still outstanding" is a counted s_waitcnt
+    // with an immediate.  No polling on the memory side: iteration i of the pose loop below (which starts when step
+    // i - 1 has completed) issues knot i + 4 into the slot step i - 1 has finished with and publishes knot i + 2, issued
+    // two iterations (~3 us) earlier; wave 0 asks for it at the end of its step i.
+    static_assert(2 * IN::NDMA <= 63 && RL_DEPTH >= 5, "vmcnt is a 6-bit counter; the look-ahead below spans 5 slots");
+    int issued = 0;
+    auto publish_loaded = [&](int target) {  // knots < target have landed (issued - target in 0..2)
+      switch (issued - target) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * IN::NDMA) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IN::NDMA) : "memory"); break;
       }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) vs[1] = target;
+    };
+    while (issued < N && issued < RL_DEPTH) issue(issued++);
+    publish_loaded(N < 3 ? N : 3);
+    // ---------------- ... and the pose chain X_{i+1} = project(X_i Exp(xi_i dt)) (the pose half of f, dyn_pose_k), one
+    // step ahead of wave 0, which produces xi_i at the end of its step i - 1 and needs X_{i+1} at the start of step
+    // i + 1.  Four lanes per trajectory, as in wave 0 (same lane -> trajectory map, lane 0 of a quad writes).
+    const int tt = lane >> 2;
+    const bool writer = (lane & 3) == 0;
+    const DynK DK = dynk_load(C);
+    State S = rl_in_state<M>(inring[0], tt);  // x^_0 = x_0
+#ifdef TOLG_STAMPS
+    unsigned long long pw[3] = {0, 0, 0}, pw_t = __builtin_amdgcn_s_memtime();
+#define PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pw[k] += t_ - pw_t; pw_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PSTAMP(k)
+#endif
+    for (int i = 0; i < N; i++) {
+      if (i > 0) {
+        bool seen = false;
+        for (int n = 0; n < RL_POLLS && !(seen = __builtin_amdgcn_readfirstlane(vs[0]) >= i); n++) __builtin_amdgcn_s_sleep(1);
+        if (!seen) return;  // wave 0 reports the failure (its own poll of sync[7] runs out)
+        asm volatile("" ::: "memory");
+        PSTAMP(0)
+        rl_get_twist(ring[i % RL_RING], tt, S.w, S.v);
+        if (issued < N) issue(issued++);  // knot i + 4, into the slot step i - 1 has finished with
+        publish_loaded(i + 3 < N ? i + 3 : N);
+        PSTAMP(1)
+      }
+      S.X = dyn_pose_k(DK, S);
+      if (writer) rl_put_pose(ring[(i + 1) % RL_RING], tt, S.X);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) vs[7] = i + 1;
+      PSTAMP(2)
     }
+#ifdef TOLG_STAMPS
+    if (blockIdx.x == 5 && lane == 0 && P.alpha_hist)
+      for (int k = 0; k < 3; k++) P.alpha_hist[(size_t)83 * P.max_iter + k] = (double)pw[k];
+#endif
     return;
   }
   // ---------------- linearisation helpers: pass g covers knots 4g .. 4g+3 (lane / 16) of the 16 trajectories (lane % 16)
@@ -2530,7 +2656,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 #ifdef TOLG_STAMPS
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); hs_work += t_ - hs_t; hs_t = t_; }
 #endif
-    if (!rl_wait_ge(vs, need)) {
+    if (!rl_wait_ge(vs, need) || !rl_wait_ge(vs + 7, need)) {  // twists (wave 0) and poses (wave 1) up to `need`
       if (mine && kk == 0) P.status[b] = TOLG_ST_INTERNAL;
       return;
     }
@@ -3056,6 +3182,7 @@ struct tolg_handle_s {
   int run_it;         // iterations issued so far
   bool running;
   int lds_per_block;  // hipDeviceAttributeMaxSharedMemoryPerBlock of the current device (160 KB on MI355X)
+  int rec_closed = 0; // the knot records were last written by the fused rollout (no defect field, see k_backward)
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
   // timing
   bool timing;
@@ -3340,6 +3467,7 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
                          double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1) {
   if (ni < 0) ni = P.N + 1;
   size_t n = (size_t)ni * P.Bp;
+  h->rec_closed = 0;  // K1 writes the defect field
   Timed t(h, st, 2);
   hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms,
                      i0, ni);
@@ -3349,6 +3477,7 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   Timed t(h, st, 0);
+  ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const bool dj = h->hc.diagJ != 0;
   const dim3 grid(P.Bp / 4), blk(64);
   if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
@@ -3416,6 +3545,7 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
         Timed t(h, st, 1);
         hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), dyn_lds, st, P, it);
         LAUNCH_CHECK();
+        h->rec_closed = 1;  // its records carry no defect field (zero by construction): K2 reads zeros instead
       }
       continue;  // the fused launch also sums the costs and does the bookkeeping of k_reduce
     } else if (!opt->line_search) {
