@@ -2395,6 +2395,22 @@ TOLG_DEV void rl_dma16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// four consecutive KB with one M0 setting: the instruction offset moves both the global and the LDS address.  base is
+// wave-uniform (SGPR pair), voff the lane's byte offset.  (M0 handling is a quarter of an LDS-DMA's issue time:
+// tools/lds_dma_microbench.hip)
+TOLG_DEV void rl_dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in a form the "s" constraint accepts
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  return reinterpret_cast<const void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
 template <int M>
 TOLG_DEV void rl_in_load(const char* slot, int tt, int q, RollIn<M>& R) {
   const int qp = (2 * q < M) ? q : M / 2 - 1;  // lanes past the last row pair re-read it (their product is unused)
@@ -2567,10 +2583,17 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     auto issue = [&](int k) {
       const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(k % RL_DEPTH) * IN::SLOT));
       const char* gk = reinterpret_cast<const char*>(P.GK + gStride * k + (size_t)(b0 >> 2) * 13 * M * 4);
+      // every instruction is issued whatever the workgroup's share (the counted vmcnt below relies on NDMA per knot):
+      // pieces of groups past the batch re-read piece 0 into their (unused) place.  A full workgroup moves its run
+      // four KB per M0 setting.
+      constexpr int QUADS = (IN::GAINS / 1024) / 4;
+      if (ntraj == 16) {
+#pragma unroll
+        for (int g4 = 0; g4 < QUADS; g4++) rl_dma16x4(uniform_ptr(gk + g4 * 4096), (unsigned)lane * 16u, dst + g4 * 4096);
+      }
 #pragma unroll
       for (int c = 0; c < (IN::GAINS + 1023) / 1024; c++) {
-        // every instruction is issued whatever the workgroup's share (the counted vmcnt below relies on NDMA per
-        // knot): pieces of groups past the batch re-read piece 0 into their (unused) place
+        if (c < 4 * QUADS && ntraj == 16) continue;
         const int ch = c * 64 + lane;
         if (ch < IN::GAINS / 16) rl_dma16(gk + (size_t)(ch < gchunks ? ch : 0) * 16, dst + c * 1024);
       }
