@@ -104,16 +104,20 @@ def measured_traffic(kernel="k_backward"):
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes).  PMC counters cannot be read
     from inside the timed process, so this is the figure of the profiled run, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
-    if not files:
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        key = (d.get("captured", ""), os.path.basename(f))  # newest capture; files without a stamp sort first
+        if best is None or key > best[0]:
+            best = (key, d, f)
+    if best is None:
         return None, None
-    try:
-        d = json.load(open(files[-1]))
-        for name, v in d["kernels"].items():
-            if kernel in name:
-                return v["hbm_bytes_per_launch_fetch_doubled"], os.path.basename(files[-1])
-    except Exception:
-        pass
+    for name, v in best[1].get("kernels", {}).items():
+        if kernel in name:
+            return v.get("hbm_bytes_per_launch_fetch_doubled"), os.path.basename(best[2])
     return None, None
 
 
