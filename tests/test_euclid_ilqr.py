@@ -94,3 +94,36 @@ def test_cartpole_swingup_matches_numpy_restatement(hessians):
     assert J_hist == [c[3] for c in calls] and J_hist[-1] < J_hist[0]
     assert xs.shape == (N + 1, 4) and us.shape == (N, 1)
 
+
+
+def test_linear_quadratic_problem_converges_to_the_riccati_solution():
+    """Known answer that owes nothing to any restatement of the solver: for x+ = A x + B u and a quadratic cost
+    the converged iLQR controls are the finite-horizon LQR controls, u_i = -K_i x_i with K_i from the backward
+    Riccati recursion (computed here with plain numpy)."""
+    rng = np.random.default_rng(7)
+    n, m, N = 4, 2, 25
+    A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    B = 0.3 * rng.standard_normal((n, m))
+    Q = np.diag([2.0, 1.0, 3.0, 0.5]); R = np.diag([0.7, 1.3]); QN = 5.0 * np.eye(n)
+    At, Bt, Qt, Rt, QNt = (torch.as_tensor(M_, dtype=torch.float64) for M_ in (A, B, Q, R, QN))
+    dyn = AutoDiffDynamics(lambda x, u, i: At @ x + Bt @ u, n, m)
+    cost = AutoDiffCost(lambda x, u, i: 0.5 * x @ Qt @ x + 0.5 * u @ Rt @ u, lambda x, i: 0.5 * x @ QNt @ x, n, m)
+    x0 = np.array([1.0, -2.0, 0.5, 1.5])
+    xs, us, J_hist, _, _ = iLQR(dyn, cost, N).fit(x0, np.zeros((N, m)), n_iterations=60, tol_J=0.0,
+                                                  on_iteration=lambda *a: a[9].append(a[3]))  # J_hist is the callback's to fill
+    # Riccati: P_N = QN, K_i = (R + B'P B)^-1 B'P A, P_i = Q + A'P(A - B K_i)
+    P = QN.copy(); K = [None] * N
+    for i in range(N - 1, -1, -1):
+        K[i] = np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
+        P = Q + A.T @ P @ (A - B @ K[i])
+    x = x0.copy(); J = 0.0; us_lqr = np.zeros((N, m))
+    for i in range(N):
+        us_lqr[i] = -K[i] @ x
+        J += 0.5 * x @ Q @ x + 0.5 * us_lqr[i] @ R @ us_lqr[i]
+        x = A @ x + B @ us_lqr[i]
+    J += 0.5 * x @ QN @ x
+    assert abs(J - 0.5 * x0 @ P @ x0) < 1e-10 * J           # the recursion above is self-consistent
+    # the line search stops once J no longer decreases in double precision: J agrees to ~1e-12, and at a quadratic
+    # optimum that pins the controls to ~sqrt(1e-12)
+    assert abs(J_hist[-1] - J) < 1e-10 * J and np.abs(us - us_lqr).max() < 1e-5
+    assert np.abs(xs[-1] - x).max() < 1e-5
