@@ -1,0 +1,519 @@
+// tolg_backward3.h -- K2, third form (round 3): the Riccati sweep of traopt_controller.py:2912-3068 for models whose
+// input matrix has one entry per column (diagonal inertia blocks: every reference script), i.e. SE3 / RigidBody / SO3
+// (m = 6) and Drone (m = 4).  Included by tolg_kernels.hip inside namespace tolg, after the K2 helpers.
+//
+// Same lane map as k_backward (16 lanes per trajectory, lane j = column j of every 12 x 12, lane 12 the vector column,
+// lane 13 the single-shooting adjoint; products by DPP row_newbcast fused into v_fmac_f64).  What changed, and why
+// (profiles/r02_final_sq_counters.json: 61 % VALU, 23 % parked on s_waitcnt, 13 % other instruction issue):
+//
+// 1. The knot records come through LDS.  k_backward fetched its fields with 22-31 gather loads per wave and knot
+//    (every lane its own 8 bytes) into a register buffer that the next knot's prefetch overwrote mid-step -- 62 VGPRs,
+//    ~55 copies out of them per knot, and a wait at the top of every step.  Here one LDS-DMA burst (4-5
+//    global_load_lds_dwordx4, 1 KB each, fully coalesced: the four trajectories of a wave own one contiguous run per
+//    knot) brings a knot into a 2-slot LDS ring a whole step ahead, and each lane picks its fields with ds_read
+//    straight into the registers that use them.  Structural zeros are read from a zeroed LDS pad.
+// 2. F_u = [0; B] with B = D S (D diagonal m x m, S a row selector), so Q_uu = 2R + D (V + mu I)_SS D is congruent to
+//    Mt = (V + mu I)_SS + 2 D^-1 R D^-1 (+ D^-1 l_uu^AL D^-1), and Q_ux = D G with G = rows S of (V + mu I) F_x.
+//    Mt's columns already sit in the lanes that hold the columns of V_SS: no T = B^T V product, no row shift; the
+//    pivots of Mt are those of Q_uu divided by positive numbers, so "every pivot > 0" is still is_pos_def(Q_uu+Q_uu^T).
+// 3. V' = Q_xx - G^T Mt^-1 G = Q_xx - Y^T Dl^-1 Y with Y = L^-1 G (Mt = L Dl L^T): only the FORWARD substitution is on
+//    the path to the next knot; the backward substitution (gains K = -D^-1 L^-T Dl^-1 Y, needed for the output only)
+//    runs beside the rank-m update.  The update term is symmetric up to the rounding of its fused multiply-adds, so
+//    what has to be symmetrised (the reference's V <- (V + V^T)/2, :3004) is Q_xx = l_xx + F_x^T V F_x alone -- and
+//    that is known long before the factorisation ends: its LDS transpose round trip, which sat on the critical path
+//    of every knot in k_backward, passes behind the factorisation here.  It cannot be dropped: the antisymmetric
+//    part of V is an unstable mode of this form of the recursion (S' = F_x^T S F_x + (B K)^T S (B K): the cross
+//    terms that make the closed loop contract are symmetric and never see it); left alone it grew from 1e-16 to
+//    1e-8 over 130-200 knots (tests/test_gpu_fused.py, test_gpu_parity.py caught it).
+template <int M>
+__host__ __device__ constexpr int urow(int u) { return (u < 3 || M == 6) ? 6 + u : 11; }  // state row driven by input u
+
+#ifndef TOLG_DPP_BUILTIN
+#define DF3(acc, p, q, L) "v_fmac_f64_dpp " acc ", " p ", " q " row_newbcast:" L " row_mask:0xf bank_mask:0xf\n\t"
+// a[i] += a[i]@lane LN * w for the rows below pivot J
+template <int M, int J, int LN>
+TOLG_DEV void ldl3_update(double (&a)[M], double w) {
+  constexpr int R = M - 1 - J;
+  if constexpr (R == 5)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%5", "%6") DF3("%1", "%1", "%5", "%6") DF3("%2", "%2", "%5", "%6")
+                     DF3("%3", "%3", "%5", "%6") DF3("%4", "%4", "%5", "%6")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]), "+v"(a[J + 5]) : "v"(w), "n"(LN));
+  if constexpr (R == 4)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%4", "%5") DF3("%1", "%1", "%4", "%5") DF3("%2", "%2", "%4", "%5")
+                     DF3("%3", "%3", "%4", "%5")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]) : "v"(w), "n"(LN));
+  if constexpr (R == 3)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%3", "%4") DF3("%1", "%1", "%3", "%4") DF3("%2", "%2", "%3", "%4")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]) : "v"(w), "n"(LN));
+  if constexpr (R == 2)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%2", "%3") DF3("%1", "%1", "%2", "%3")
+                 : "+v"(a[J + 1]), "+v"(a[J + 2]) : "v"(w), "n"(LN));
+  if constexpr (R == 1)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%1", "%2") : "+v"(a[J + 1]) : "v"(w), "n"(LN));
+}
+// y += sum_{k < I} p@lane urow(k) * q[k]  (row I of the forward substitution; p = this lane's a[I])
+template <int M, int I>
+TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
+  if constexpr (I == 1)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
+  if constexpr (I == 2)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0)), "n"(urow<M>(1)));
+  if constexpr (I == 3)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%5") DF3("%0", "%1", "%3", "%6") DF3("%0", "%1", "%4", "%7")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "n"(urow<M>(0)), "n"(urow<M>(1)), "n"(urow<M>(2)));
+  if constexpr (I == 4)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%6") DF3("%0", "%1", "%3", "%7") DF3("%0", "%1", "%4", "%8")
+                     DF3("%0", "%1", "%5", "%9")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "n"(urow<M>(0)), "n"(urow<M>(1)),
+                   "n"(urow<M>(2)), "n"(urow<M>(3)));
+  if constexpr (I == 5)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%7") DF3("%0", "%1", "%3", "%8") DF3("%0", "%1", "%4", "%9")
+                     DF3("%0", "%1", "%5", "%10") DF3("%0", "%1", "%6", "%11")
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "n"(urow<M>(0)),
+                   "n"(urow<M>(1)), "n"(urow<M>(2)), "n"(urow<M>(3)), "n"(urow<M>(4)));
+}
+// t += sum_{k > I} a[k]@lane LN * x[k]  (row I of the back substitution: column I of the factor lives in lane LN = urow(I))
+template <int M, int I, int LN>
+TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
+  constexpr int R = M - 1 - I;
+  if constexpr (R == 1) asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(t) : "v"(a[I + 1]), "v"(x[I + 1]), "n"(LN));
+  if constexpr (R == 2)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%3", "%5") DF3("%0", "%2", "%4", "%5")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(x[I + 1]), "v"(x[I + 2]), "n"(LN));
+  if constexpr (R == 3)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%4", "%7") DF3("%0", "%2", "%5", "%7") DF3("%0", "%3", "%6", "%7")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(x[I + 1]), "v"(x[I + 2]), "v"(x[I + 3]), "n"(LN));
+  if constexpr (R == 4)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%5", "%9") DF3("%0", "%2", "%6", "%9") DF3("%0", "%3", "%7", "%9")
+                     DF3("%0", "%4", "%8", "%9")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(x[I + 1]), "v"(x[I + 2]),
+                   "v"(x[I + 3]), "v"(x[I + 4]), "n"(LN));
+  if constexpr (R == 5)
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%6", "%11") DF3("%0", "%2", "%7", "%11") DF3("%0", "%3", "%8", "%11")
+                     DF3("%0", "%4", "%9", "%11") DF3("%0", "%5", "%10", "%11")
+                 : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(a[I + 5]), "v"(x[I + 1]),
+                   "v"(x[I + 2]), "v"(x[I + 3]), "v"(x[I + 4]), "v"(x[I + 5]), "n"(LN));
+}
+#else
+template <int M, int J, int LN>
+TOLG_DEV void ldl3_update(double (&a)[M], double w) {
+#pragma unroll
+  for (int i = J + 1; i < M; i++) a[i] += bcast<LN>(a[i]) * w;
+}
+template <int M, int I>
+TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
+  if constexpr (I > 0) y += bcast<urow<M>(0)>(p) * q[0];
+  if constexpr (I > 1) y += bcast<urow<M>(1)>(p) * q[1];
+  if constexpr (I > 2) y += bcast<urow<M>(2)>(p) * q[2];
+  if constexpr (I > 3) y += bcast<urow<M>(3)>(p) * q[3];
+  if constexpr (I > 4) y += bcast<urow<M>(4)>(p) * q[4];
+}
+template <int M, int I, int LN>
+TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
+#pragma unroll
+  for (int k = I + 1; k < M; k++) t += bcast<LN>(a[k]) * x[k];
+}
+#endif
+
+// Mt (m x m, column c in lane urow(c)) factored where it lies: right-looking L Dl L^T.  wm[J] is this lane's update
+// mask for pivot J: -1 for the columns right of the pivot, 0 for every other lane (their rows below J are final factor
+// entries, or not part of Mt at all).  On return a[i] (i > c) of lane urow(c) holds L[i][c] Dl_c, rinv[J] = 1 / Dl_J in
+// every lane.  Returns "every pivot > 0".
+template <int M, int J = 0>
+TOLG_DEV bool ldl3_factor(double (&a)[M], double (&rinv)[M], const double (&wm)[M], bool ok = true) {
+  const double d = bcast<urow<M>(J)>(a[J]);
+  ok = ok && (d > 0.0);
+  rinv[J] = rcp_nr(d);  // a non-positive pivot leaves garbage behind it: the caller discards the factors when !ok
+  if constexpr (J + 1 < M) {
+    const double w = (a[J] * wm[J]) * rinv[J];
+    ldl3_update<M, J, urow<M>(J)>(a, w);
+    return ldl3_factor<M, J + 1>(a, rinv, wm, ok);
+  } else {
+    return ok;
+  }
+}
+// forward substitution in place: y <- L^-1 y, zn_k = -y_k / Dl_k (nri = -rinv, zeroed in the adjoint lane)
+template <int M>
+TOLG_DEV void ldl3_forward(const double (&a)[M], const double (&nri)[M], double (&y)[M], double (&zn)[M]) {
+  zn[0] = y[0] * nri[0];
+  if constexpr (M > 1) { ldl3_fwd_row<M, 1>(y[1], a[1], zn); zn[1] = y[1] * nri[1]; }
+  if constexpr (M > 2) { ldl3_fwd_row<M, 2>(y[2], a[2], zn); zn[2] = y[2] * nri[2]; }
+  if constexpr (M > 3) { ldl3_fwd_row<M, 3>(y[3], a[3], zn); zn[3] = y[3] * nri[3]; }
+  if constexpr (M > 4) { ldl3_fwd_row<M, 4>(y[4], a[4], zn); zn[4] = y[4] * nri[4]; }
+  if constexpr (M > 5) { ldl3_fwd_row<M, 5>(y[5], a[5], zn); zn[5] = y[5] * nri[5]; }
+}
+// back substitution: x = -L^-T zn  (= Mt^-1 of the right-hand side), x_i = -(zn_i + (1 / Dl_i) sum_{k>i} a[k]@i x_k)
+template <int M>
+TOLG_DEV void ldl3_backward(const double (&a)[M], const double (&rinv)[M], const double (&zn)[M], double (&x)[M]) {
+  x[M - 1] = -zn[M - 1];
+  if constexpr (M > 1) { double t = 0; ldl3_bwd_row<M, M - 2, urow<M>(M - 2)>(t, a, x); x[M - 2] = -fma(rinv[M - 2], t, zn[M - 2]); }
+  if constexpr (M > 2) { double t = 0; ldl3_bwd_row<M, M - 3, urow<M>(M - 3)>(t, a, x); x[M - 3] = -fma(rinv[M - 3], t, zn[M - 3]); }
+  if constexpr (M > 3) { double t = 0; ldl3_bwd_row<M, M - 4, urow<M>(M - 4)>(t, a, x); x[M - 4] = -fma(rinv[M - 4], t, zn[M - 4]); }
+  if constexpr (M > 4) { double t = 0; ldl3_bwd_row<M, M - 5, urow<M>(M - 5)>(t, a, x); x[M - 5] = -fma(rinv[M - 5], t, zn[M - 5]); }
+  if constexpr (M > 5) { double t = 0; ldl3_bwd_row<M, M - 6, urow<M>(M - 6)>(t, a, x); x[M - 6] = -fma(rinv[M - 6], t, zn[M - 6]); }
+}
+
+// LDS slot: up to 5 KB of records (REC_FMAX fields x 32 bytes = 4288), then a 256-byte pad of zeros at the same
+// offset in both slots (lane offsets are slot-independent; the slot base is an instruction immediate)
+enum { B3_DATA = 5120, B3_ZBYTES = 256, B3_SLOT = B3_DATA + B3_ZBYTES,
+       // transpose scratch of the symmetrisation: [trajectory][row][14] doubles (even stride: a row is six aligned
+       // 16-byte pairs), then a dump for the writes of the lanes that hold no matrix column
+       B3_TRS = 14, B3_TR = 2 * B3_SLOT, B3_TRBYTES = 4 * 12 * B3_TRS * 8, B3_DUMP = B3_TR + B3_TRBYTES,
+       B3_LDS = B3_DUMP + 12 * B3_TRS * 8 };
+
+// GRAV: the model has a gravity block A21 in F_x (Drone / RigidBody); SE3 / SO3 instantiate without it.
+// AL: augmented-Lagrangian solve (the records carry the l_uu diagonal; decides the record size with M and GRAV).
+template <int M, bool GRAV, bool AL>
+__global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
+  // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
+  // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here
+  const int ms = flags & 1;
+  const bool closed = (flags & 2) != 0;
+  const DConsts& C = *(const DConsts*)P.c;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
+  const bool act = P.active[b] != 0;
+  if (!__any(act)) return;
+  const int N = P.N;
+  // LDS: two record slots (one knot of this wave's four trajectories each, exactly as it lies in REC), a zeroed pad
+  // that stands in for structurally-zero fields
+  __shared__ __attribute__((aligned(16))) char lds[B3_LDS];
+  if (lane < B3_ZBYTES / 8) {
+    reinterpret_cast<double*>(lds + B3_DATA)[lane] = 0.0;
+    reinterpret_cast<double*>(lds + B3_SLOT + B3_DATA)[lane] = 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+  // ---- lane-dependent constants
+  const double m12 = (j < 12) ? 1.0 : 0.0;  // matrix columns
+  // input owned by this lane's column (the lane holds column c of Mt), -1 if none
+  int mycol = -1;
+#pragma unroll
+  for (int u = 0; u < M; u++) if (j == urow<M>(u)) mycol = u;
+  // b_u = F_u[urow(u)][u] (wave-uniform), and the per-lane constants: 2 W2 column (lanes 6..11), the column of
+  // Rt = 2 D^-1 R D^-1 (lanes that hold a column of Mt), the update masks of the factorisation
+  double bu[M], ibu[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) { bu[u] = fu_entry<M>(C, urow<M>(u) - 6, u); ibu[u] = 1.0 / bu[u]; }
+  double kBW[6], Rt[M], wm[M];
+#pragma unroll
+  for (int r = 0; r < 6; r++) kBW[r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;
+  {
+    double ibc = 0.0;
+#pragma unroll
+    for (int u = 0; u < M; u++) if (mycol == u) ibc = ibu[u];
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      Rt[u] = (mycol >= 0) ? 2.0 * C.R[u * M + (mycol >= 0 ? mycol : 0)] * ibu[u] * ibc : 0.0;
+      wm[u] = (mycol > u) ? -1.0 : 0.0;
+    }
+  }
+  // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
+  int fT = REC_D, fM = REC_D + 3;
+  bool hT = false, hM = false;
+  if (j < 3) { fT = REC_RI + 3 * j; fM = REC_TRI + 3 * j; hT = true; hM = true; }
+  else if (j < 6) { fM = REC_RI + 3 * (j - 3); hM = true; }
+  else if (j < 9) { fT = REC_JR + 3 * (j - 6); fM = REC_QR + 3 * (j - 6); hT = true; hM = true; }
+  else if (j < 12) { fM = REC_JR + 3 * (j - 9); hM = true; }
+  else if (j == 12 && !closed) { hT = true; hM = true; }
+  const bool hasB = (j >= 6 && j < 12) || (j == 12 && !closed), isVec = (j == 12 || j == 13);
+  const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
+  const bool hL = (j < 6 || isVec);
+  // LDS byte offsets inside a slot (the slot base is added as an immediate); fields that are structurally zero for
+  // this lane point into the zeroed pad.  Loads of pairs use bases on even fields (REC_A22, REC_D, REC_LX, REC_LU).
+  const unsigned lg = (unsigned)g * 16u;
+  const unsigned ZP = (unsigned)B3_DATA;
+  unsigned oT[3], oM[3], oL[6];
+#pragma unroll
+  for (int r = 0; r < 3; r++) { oT[r] = hT ? lg + FOFF(fT + r) : ZP; oM[r] = hM ? lg + FOFF(fM + r) : ZP; }
+#pragma unroll
+  for (int r = 0; r < 6; r++) oL[r] = hL ? lg + FOFF((j < 6) ? REC_LXX + sym6(r, j) : REC_LX + r) : ZP;
+  const unsigned oB = hasB ? lg + FOFF(fB) : ZP;                 // rows 6..11 of the column: three 16-byte pairs
+  const unsigned oV = isVec ? lg + FOFF(REC_LX + 6) : ZP;        // l_x[6:12] (vector columns)
+  const unsigned oU = isVec ? lg + FOFF(REC_LU) : ZP;            // l_u (vector columns)
+  const unsigned oG = lg + FOFF(REC_LU + M);                     // gravity direction (every lane), GRAV only
+  constexpr bool al = AL;
+  constexpr unsigned blockBytes = (unsigned)rec_fields(M, GRAV, AL) * 32u;  // one knot of this wave's four trajectories
+  const unsigned oUU = (al && mycol >= 0) ? lg + FOFF(P.fLUU + (mycol >= 0 ? mycol : 0)) : ZP;  // l_uu^AL[c][c] in the lane of Mt's column c
+  // symmetrisation scratch: lane j < 12 writes its column (entry r at row r) and reads row j back as six pairs;
+  // the vector lanes write into the dump, read zeros and scale by 1 instead of 1/2
+  const unsigned wTR = (j < 12) ? (unsigned)B3_TR + ((unsigned)g * 12u * B3_TRS + (unsigned)j) * 8u : (unsigned)B3_DUMP;
+  const unsigned rTR = (j < 12) ? (unsigned)B3_TR + ((unsigned)g * 12u * B3_TRS + (unsigned)j * B3_TRS) * 8u : ZP;
+  const double hsym = (j < 12) ? 0.5 : 1.0;
+  const unsigned sB = (unsigned)P.Bp * 8u;
+  const unsigned vr = REC_VR(b);
+  const unsigned vG = GK_VG(b, M) + GOFF(0, (j < 13 ? j : 12), M);
+  const size_t recStride = (size_t)P.recF * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  double Cg[GRAV ? 3 : 1][6];
+  if constexpr (GRAV) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) Cg[a][r] = (j < 3) ? C.Llin[a][6 * r + (j < 3 ? j : 0)] : 0.0;
+  }
+  double mu = P.mu[b], delta = P.delta[b];
+  int warned = 0;
+
+  // one knot of records into LDS slot s (wave-uniform source, 16 bytes per lane and instruction)
+  auto dma_knot = [&](int i, int s) {
+    const char* src = reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)s * B3_SLOT));
+    rl_dma16x4(uniform_ptr(src), (unsigned)lane * 16u, dst);
+    if constexpr (blockBytes > 4096u) rl_dma16(src + 4096 + (size_t)lane * 16, dst + 4096);
+  };
+
+  // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
+  double V[12];
+  {
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * N, (unsigned)P.recF * sB);
+    const unsigned OOB = 0x40000000u;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const int fl = (j < 6) ? REC_LXX + sym6(r, j) : REC_LX + r;
+      double t1 = bld(rR, hL ? vr + FOFF(fl) : OOB, 0), t2 = bld(rR, isVec ? vr + FOFF(REC_LX + 6 + r) : OOB, 0);
+      V[r] = t1;
+      double p2 = (j >= 6 && j < 12) ? 2.0 * C.P2[6 * r + (j - 6)] : 0.0;
+      V[6 + r] = t2 + p2;
+    }
+  }
+  double gsum = 0;
+  double Kst[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) Kst[u] = 0;
+  auto store_gains = [&](int knot) {
+    if (act && j < 13) {
+      __amdgpu_buffer_rsrc_t rGs = mkbuf(P.GK + gStride * knot, 13 * M * sB);
+#pragma unroll
+      for (int u = 0; u < M; u += 2) bst2(rGs, vG, GOFF(u, 0, M), Kst[u], Kst[u + 1]);
+    }
+  };
+#ifdef TOLG_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- one knot.  SLOT (compile time): the LDS slot that holds knot i; the loop below is unrolled by two.
+  auto step = [&](int i, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const char* sl = lds + SLOT * B3_SLOT;
+    auto ld = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(sl + off); };
+    auto ld2 = [&](unsigned off, int k, double& x0, double& x1) {  // pair k of a run that starts on an even field
+      const f64x2 w = *reinterpret_cast<const f64x2*>(sl + off + k * 64);
+      x0 = w.x; x1 = w.y;
+    };
+    // The records of knot i were requested two steps ago; the memory queue retires in order, so "everything but
+    // the last step's gain stores and record request" is a counted wait.  (Step 0 is preceded by a step that
+    // requested nothing.)
+    if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + (blockBytes > 4096u ? 5 : 4)) : "memory");
+    double A[12], Qh[12], lu[M], luu_i = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { A[r] = ld(oT[r]); A[3 + r] = ld(oM[r]); }
+#pragma unroll
+    for (int r = 0; r < 6; r += 2) ld2(oB, r / 2, A[6 + r], A[7 + r]);
+#pragma unroll
+    for (int r = 0; r < 6; r++) Qh[r] = ld(oL[r]);
+#pragma unroll
+    for (int r = 0; r < 6; r += 2) ld2(oV, r / 2, Qh[6 + r], Qh[7 + r]);
+#pragma unroll
+    for (int a = 0; a < M; a += 2) ld2(oU, a / 2, lu[a], lu[a + 1]);
+    if constexpr (al) luu_i = ld(oUU);
+    if constexpr (GRAV) {
+      double gv[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) gv[a] = *reinterpret_cast<const double*>(sl + oG + (FOFF(REC_LU + M + a) - FOFF(REC_LU + M)));
+#pragma unroll
+      for (int r = 0; r < 6; r++) A[6 + r] += gv[0] * Cg[0][r] + gv[1] * Cg[1][r] + gv[2] * Cg[2][r];
+    }
+    STAMP(0)
+    // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; the adjoint passes through)
+    double Z[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++) Z[r] = (1.0 - m12) * V[r];
+    rank1_bk3_0(Z, V, A[0], A[1], A[2]); rank1_bk3_3(Z, V, A[3], A[4], A[5]);
+    rank1_bk3_6(Z, V, A[6], A[7], A[8]); rank1_bk3_9(Z, V, A[9], A[10], A[11]);
+    STAMP(1)
+    // the slot is consumed (every ds_read above has returned: Z needed them): last knot's gains go out, then the
+    // records of knot i - 2 come into this slot.  Stores first: the wait at the top of a step covers both, in order.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (i < N - 1) store_gains(i + 1);
+    if (i >= 2) dma_knot(i - 2, SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- regularised G = rows S of (V + mu I)[F_x | d] (+ D^-1 l_u in the vector columns), Mt; PD test
+    // (traopt_controller.py:2964-2995, :3052-3060)
+    double Y[M], Uf[M], rinv[M];
+    bool use_lu = false;
+    double mu_used = 0.0;
+    auto build = [&](double mu_, double (&Gm)[M], double (&Mt)[M]) {
+      const double muA = m12 * mu_;
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        Gm[u] = fma(lu[u], ibu[u], Z[urow<M>(u)]);
+        Mt[u] = V[urow<M>(u)] + Rt[u];
+      }
+      if (__any(mu_ != 0.0)) {
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          Gm[u] = fma(muA, A[urow<M>(u)], Gm[u]);
+          Mt[u] += (mycol == u) ? mu_ : 0.0;
+        }
+      }
+      if constexpr (al) {
+#pragma unroll
+        for (int u = 0; u < M; u++) Mt[u] += (mycol == u) ? luu_i * ibu[u] * ibu[u] : 0.0;
+      }
+    };
+    auto attempt = [&]() -> bool {
+      mu_used = mu;
+      build(mu, Y, Uf);
+      return ldl3_factor<M>(Uf, rinv, wm);
+    };
+    // regularisation schedule (traopt_controller.py:2975-2995); returns true when this knot is settled
+    auto schedule = [&](bool pd) -> bool {
+      if (!pd) {
+        delta = fmax(1.0, delta) * 2.0;
+        mu = fmax(1e-6, mu * delta);
+        if (P.max_reg > 0 && mu >= P.max_reg) { warned = 1; use_lu = true; return true; }
+        return false;
+      }
+      delta = fmin(1.0, delta) * 0.5;
+      mu *= delta;
+      if (mu <= 1e-6) mu = 0.0;
+      return true;
+    };
+    // ---- Qh = [l_xx | l_x] + F_x^T Z   (F_x = [Ri 0 Jr 0; TRi Ri Qr Jr; A21 0 A22 A22]: zero 3-row blocks skipped)
+    {
+      const double a0[3] = {A[0], A[1], A[2]}, z0[3] = {Z[0], Z[1], Z[2]}, a1[3] = {A[3], A[4], A[5]}, z1[3] = {Z[3], Z[4], Z[5]};
+      const double a2[6] = {A[6], A[7], A[8], A[9], A[10], A[11]}, z2[6] = {Z[6], Z[7], Z[8], Z[9], Z[10], Z[11]};
+      rank1_bi_02x3(Qh, a0, z0);
+      rank1_bi_x3(Qh, a1, z1);
+      if constexpr (GRAV) rank1_bi_023x6(Qh, a2, z2);
+      else rank1_bi_23x6(Qh, a2, z2);
+#pragma unroll
+      for (int r = 0; r < 6; r++) Qh[6 + r] += kBW[r];
+      // on its way through LDS for the symmetrisation (read back after the factorisation)
+#pragma unroll
+      for (int r = 0; r < 12; r++) *reinterpret_cast<double*>(lds + wTR + r * (B3_TRS * 8)) = Qh[r];
+    }
+    STAMP(2)
+    bool done = true;
+    {
+      const bool pd = attempt();
+      if (act) done = schedule(pd);
+    }
+    if (!__all(done)) {
+      for (;;) {
+        if (!done) done = schedule(attempt());
+        if (__all(done)) break;
+      }
+    }
+    STAMP(3)
+    // gradient term: ||Q_u|| = ||D G|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
+    {
+      double s = 0;
+#pragma unroll
+      for (int u = 0; u < M; u++) { const double q = bu[u] * Y[u]; s = fma(q, q, s); }
+      gsum += (s > 0.0) ? s * rsqrt_nr(s) : 0.0;  // sqrt(s) without the IEEE sqrt sequence (2 ulp)
+    }
+    double zn[M], X[M];
+    if (__any(use_lu)) {
+      // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics (rare path).  Mt is rebuilt -- the
+      // factorisation ran in place -- replicated to every lane and solved by LU with partial pivoting; the value
+      // update takes the unfactored form V' = Q_xx - G^T x.
+      double Gk[M], Mc[M], Ac[M][M], Xl[M], nri[M];
+      build(mu_used, Gk, Mc);
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        Xl[u] = Gk[u];
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+          double v = 0;
+          if (c == 0) v = bcast<urow<M>(0)>(Mc[u]);
+          if (c == 1) v = bcast<urow<M>(1)>(Mc[u]);
+          if (c == 2) v = bcast<urow<M>(2)>(Mc[u]);
+          if (c == 3) v = bcast<urow<M>(3)>(Mc[u]);
+          if constexpr (M > 4) {
+            if (c == 4) v = bcast<urow<M>(4)>(Mc[u]);
+            if (c == 5) v = bcast<urow<M>(5)>(Mc[u]);
+          }
+          Ac[u][c] = v;
+        }
+      }
+      lu_solve<M>(Ac, Xl);
+#pragma unroll
+      for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : -rinv[u];
+      ldl3_forward<M>(Uf, nri, Y, zn);
+      ldl3_backward<M>(Uf, rinv, zn, X);
+      // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that the one rank-m update below serves both
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        const double xl = (j == 13) ? 0.0 : Xl[u];
+        Y[u] = use_lu ? Gk[u] : Y[u];
+        zn[u] = use_lu ? -xl : zn[u];
+        X[u] = use_lu ? xl : X[u];
+      }
+    } else {
+      double nri[M];
+#pragma unroll
+      for (int u = 0; u < M; u++) nri[u] = -rinv[u];
+      if (!ms) {  // single shooting: the adjoint lane takes no gain correction
+#pragma unroll
+        for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : nri[u];
+      }
+      ldl3_forward<M>(Uf, nri, Y, zn);
+    }
+    STAMP(4)
+    // ---- Q_xx <- (Q_xx + Q_xx^T) / 2 (matrix columns), then V <- Qh - Y^T Dl^-1 Y  (== Eq. 11b/11c of
+    // traopt_controller.py:2998-3004 for the exact gains)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const f64x2 t = *reinterpret_cast<const f64x2*>(lds + rTR + 16 * k);
+      Qh[2 * k] = hsym * (Qh[2 * k] + t.x);
+      Qh[2 * k + 1] = hsym * (Qh[2 * k + 1] + t.y);
+    }
+    if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
+    else rank1_bi_x4(Qh, Y, zn);
+    if (!__any(use_lu)) ldl3_backward<M>(Uf, rinv, zn, X);
+    // gains [K | k] = -D^-1 Mt^-1 G
+#pragma unroll
+    for (int u = 0; u < M; u++) Kst[u] = -ibu[u] * X[u];
+#pragma unroll
+    for (int r = 0; r < 12; r++) V[r] = Qh[r];
+    STAMP(5)
+  };
+
+  // prologue: knots N-1 and N-2 into the two slots
+  dma_knot(N - 1, (N - 1) & 1);
+  if (N >= 2) dma_knot(N - 2, (N - 2) & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int i = N - 1;
+  if (i & 1) { step(i, std::integral_constant<int, 1>()); i--; }
+  for (; i >= 1; i -= 2) {
+    step(i, std::integral_constant<int, 0>());
+    step(i - 1, std::integral_constant<int, 1>());
+  }
+  if (i == 0) step(0, std::integral_constant<int, 0>());
+  store_gains(0);
+#ifdef TOLG_STAMPS
+  STAMP(7)
+  if (blockIdx.x == 7 && lane == 0 && P.mu_hist) { for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st_acc[k]; }
+#endif
+  // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
+  double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;
+  if (act && j == 0) {
+    P.mu[b] = mu;
+    P.delta[b] = delta;
+    P.grad[b] = grad;
+    if (warned) P.status[b] = TOLG_ST_MAXREG;
+    if (it >= 0 && b < P.B) {
+      if (P.grad_hist) P.grad_hist[(size_t)b * (P.max_iter + 1) + it] = grad;
+      if (P.mu_hist && it < P.max_iter) P.mu_hist[(size_t)b * P.max_iter + it] = mu;
+    }
+    if (it >= 0) {
+      bool conv = ms ? (grad < P.tol_grad && P.dn[b] < P.tol_defect) : (grad < P.tol_grad);
+      if (conv) { P.conv[b] = 1; P.active[b] = 0; }
+    }
+  }
+}

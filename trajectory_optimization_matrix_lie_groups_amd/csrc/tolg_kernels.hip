@@ -148,7 +148,7 @@ enum {
   REC_BU = REC_TRI
 };
 __host__ __device__ inline int rec_rte(int m) { return REC_LU + m; }
-__host__ __device__ inline int rec_fields(int m, bool grav, bool al) { return REC_BASE + m + (grav ? 4 : 0) + (al ? m : 0); }
+__host__ __device__ constexpr int rec_fields(int m, bool grav, bool al) { return REC_BASE + m + (grav ? 4 : 0) + (al ? m : 0); }
 // Records and gains are interleaved by four trajectories and by field pairs:
 // REC [knot][b / 4][field / 2][b % 4][field % 2], GK [knot][b / 4][column j][row u / 2][b % 4][u % 2].
 // The four trajectories of one K2 wavefront then own one contiguous run per knot (every 64-byte
@@ -2411,6 +2411,8 @@ TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in
   return reinterpret_cast<const void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
+#include "tolg_backward3.h"
+
 template <int M>
 TOLG_DEV void rl_in_load(const char* slot, int tt, int q, RollIn<M>& R) {
   const int qp = (2 * q < M) ? q : M / 2 - 1;  // lanes past the last row pair re-read it (their product is unused)
@@ -3503,6 +3505,22 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
   ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const bool dj = h->hc.diagJ != 0;
   const dim3 grid(P.Bp / 4), blk(64);
+#ifndef TOLG_K2_OLD
+  // diagonal inertia blocks and a constant input matrix (every reference script except the pendulum): the third form
+  // of the sweep (tolg_backward3.h).  Dense inertia and the pendulum keep k_backward.
+  if (dj && h->prob.kind != TOLG_DYN_PENDULUM3D) {
+    const bool al = P.al_lb != nullptr;
+    if (h->hc.grav == 0.0) {
+      if (al) hipLaunchKernelGGL((k_backward3<M, false, true>), grid, blk, 0, st, P, it, ms);
+      else hipLaunchKernelGGL((k_backward3<M, false, false>), grid, blk, 0, st, P, it, ms);
+    } else {
+      if (al) hipLaunchKernelGGL((k_backward3<M, true, true>), grid, blk, 0, st, P, it, ms);
+      else hipLaunchKernelGGL((k_backward3<M, true, false>), grid, blk, 0, st, P, it, ms);
+    }
+    LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
     if (dj) hipLaunchKernelGGL((k_backward<6, true, true, true>), grid, blk, 0, st, P, it, ms);
     else hipLaunchKernelGGL((k_backward<6, true, true, false>), grid, blk, 0, st, P, it, ms);
