@@ -124,7 +124,9 @@ template <int M, int J = 0>
 TOLG_DEV bool ldl3_factor(double (&a)[M], double (&rinv)[M], const double (&wm)[M], bool ok = true) {
   const double d = bcast<urow<M>(J)>(a[J]);
   ok = ok && (d > 0.0);
-  rinv[J] = rcp_nr(d);  // a non-positive pivot leaves garbage behind it: the caller discards the factors when !ok
+  // a non-positive pivot leaves garbage behind it: the caller discards the factors when !ok.  (One Newton step
+  // instead of two -- 2.2e-15 relative, tools/rcp_accuracy_check.hip -- was measured and is no faster: 0.364 vs 0.360 ms.)
+  rinv[J] = rcp_nr(d);
   if constexpr (J + 1 < M) {
     const double w = (a[J] * wm[J]) * rinv[J];
     ldl3_update<M, J, urow<M>(J)>(a, w);
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     if (i < N - 1) store_gains(i + 1);
     if (i >= 2) dma_knot(i - 2, SLOT);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(2)
     // ---- regularised G = rows S of (V + mu I)[F_x | d] (+ D^-1 l_u in the vector columns), Mt; PD test
     // (traopt_controller.py:2964-2995, :3052-3060)
     double Y[M], Uf[M], rinv[M];
@@ -384,6 +387,9 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       return true;
     };
     // ---- Qh = [l_xx | l_x] + F_x^T Z   (F_x = [Ri 0 Jr 0; TRi Ri Qr Jr; A21 0 A22 A22]: zero 3-row blocks skipped)
+#pragma unroll
+    for (int r = 0; r < 6; r++) Qh[6 + r] += kBW[r];
+    bool done = true;
     {
       const double a0[3] = {A[0], A[1], A[2]}, z0[3] = {Z[0], Z[1], Z[2]}, a1[3] = {A[3], A[4], A[5]}, z1[3] = {Z[3], Z[4], Z[5]};
       const double a2[6] = {A[6], A[7], A[8], A[9], A[10], A[11]}, z2[6] = {Z[6], Z[7], Z[8], Z[9], Z[10], Z[11]};
@@ -391,38 +397,68 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       rank1_bi_x3(Qh, a1, z1);
       if constexpr (GRAV) rank1_bi_023x6(Qh, a2, z2);
       else rank1_bi_23x6(Qh, a2, z2);
-#pragma unroll
-      for (int r = 0; r < 6; r++) Qh[6 + r] += kBW[r];
-      // on its way through LDS for the symmetrisation (read back after the factorisation)
+    }
+    // Q_xx on its way through LDS for the symmetrisation: written here, read back (transposed) a few hundred cycles
+    // later -- behind the factorisation / the gradient term / the forward substitution, not in front of the next knot
+    // Every second knot only (the steps of slot 0): between two symmetrisations the antisymmetric part grows by the
+    // factor of two knots (~1.2 measured, 4 at worst), which leaves it at rounding level.
+#ifdef TOLG_K3_SYM1
+    constexpr bool SYM = true;
+#else
+    constexpr bool SYM = SLOT == 0;
+#endif
+    if constexpr (SYM) {
 #pragma unroll
       for (int r = 0; r < 12; r++) *reinterpret_cast<double*>(lds + wTR + r * (B3_TRS * 8)) = Qh[r];
     }
-    STAMP(2)
-    bool done = true;
+    double T[12];
+    auto read_T = [&]() {
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const f64x2 t = *reinterpret_cast<const f64x2*>(lds + rTR + 16 * k);
+        T[2 * k] = t.x; T[2 * k + 1] = t.y;
+      }
+    };
+    auto symmetrise = [&]() {
+      if constexpr (!SYM) return;
+      read_T();
+#pragma unroll
+      for (int r = 0; r < 12; r++) Qh[r] = hsym * (Qh[r] + T[r]);
+    };
     {
       const bool pd = attempt();
       if (act) done = schedule(pd);
     }
+    STAMP(3)
     if (!__all(done)) {
       for (;;) {
         if (!done) done = schedule(attempt());
         if (__all(done)) break;
       }
     }
-    STAMP(3)
     // gradient term: ||Q_u|| = ||D G|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
     {
       double s = 0;
 #pragma unroll
       for (int u = 0; u < M; u++) { const double q = bu[u] * Y[u]; s = fma(q, q, s); }
-      gsum += (s > 0.0) ? s * rsqrt_nr(s) : 0.0;  // sqrt(s) without the IEEE sqrt sequence (2 ulp)
+      // sqrt(s) = s rsqrt(s), v_rsq_f64 + one refinement step (4e-15 relative: the gradient norm is compared with 1e-6)
+      double y = __builtin_amdgcn_rsq(s);
+      { const double g_ = s * y, h_ = 0.5 * y; y = 2.0 * fma(h_, fma(-h_, g_, 0.5), h_); }
+      gsum += (s > 0.0) ? s * y : 0.0;
     }
-    double zn[M], X[M];
+    STAMP(4)
+    double zn[M], nri[M];
+#pragma unroll
+    for (int u = 0; u < M; u++) nri[u] = -rinv[u];
+    if (!ms || __any(use_lu)) {  // the single-shooting adjoint lane takes no gain correction
+#pragma unroll
+      for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : nri[u];
+    }
     if (__any(use_lu)) {
       // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics (rare path).  Mt is rebuilt -- the
       // factorisation ran in place -- replicated to every lane and solved by LU with partial pivoting; the value
       // update takes the unfactored form V' = Q_xx - G^T x.
-      double Gk[M], Mc[M], Ac[M][M], Xl[M], nri[M];
+      double Gk[M], Mc[M], Ac[M][M], Xl[M], X[M];
       build(mu_used, Gk, Mc);
 #pragma unroll
       for (int u = 0; u < M; u++) {
@@ -442,8 +478,6 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
         }
       }
       lu_solve<M>(Ac, Xl);
-#pragma unroll
-      for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : -rinv[u];
       ldl3_forward<M>(Uf, nri, Y, zn);
       ldl3_backward<M>(Uf, rinv, zn, X);
       // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that the one rank-m update below serves both
@@ -452,36 +486,27 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
         const double xl = (j == 13) ? 0.0 : Xl[u];
         Y[u] = use_lu ? Gk[u] : Y[u];
         zn[u] = use_lu ? -xl : zn[u];
-        X[u] = use_lu ? xl : X[u];
+        Kst[u] = -ibu[u] * (use_lu ? xl : X[u]);
       }
+      symmetrise();
+      if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
+      else rank1_bi_x4(Qh, Y, zn);
     } else {
-      double nri[M];
-#pragma unroll
-      for (int u = 0; u < M; u++) nri[u] = -rinv[u];
-      if (!ms) {  // single shooting: the adjoint lane takes no gain correction
-#pragma unroll
-        for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : nri[u];
-      }
+      // ---- Q_xx <- (Q_xx + Q_xx^T) / 2, V <- Qh - Y^T Dl^-1 Y (== Eq. 11b/11c of traopt_controller.py:2998-3004 for the
+      // exact gains), then the back substitution for the gains
       ldl3_forward<M>(Uf, nri, Y, zn);
-    }
-    STAMP(4)
-    // ---- Q_xx <- (Q_xx + Q_xx^T) / 2 (matrix columns), then V <- Qh - Y^T Dl^-1 Y  (== Eq. 11b/11c of
-    // traopt_controller.py:2998-3004 for the exact gains)
+      symmetrise();
+      STAMP(5)
+      double X[M];
+      if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
+      else rank1_bi_x4(Qh, Y, zn);
+      ldl3_backward<M>(Uf, rinv, zn, X);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const f64x2 t = *reinterpret_cast<const f64x2*>(lds + rTR + 16 * k);
-      Qh[2 * k] = hsym * (Qh[2 * k] + t.x);
-      Qh[2 * k + 1] = hsym * (Qh[2 * k + 1] + t.y);
+      for (int u = 0; u < M; u++) Kst[u] = -ibu[u] * X[u];
     }
-    if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
-    else rank1_bi_x4(Qh, Y, zn);
-    if (!__any(use_lu)) ldl3_backward<M>(Uf, rinv, zn, X);
-    // gains [K | k] = -D^-1 Mt^-1 G
-#pragma unroll
-    for (int u = 0; u < M; u++) Kst[u] = -ibu[u] * X[u];
 #pragma unroll
     for (int r = 0; r < 12; r++) V[r] = Qh[r];
-    STAMP(5)
+    STAMP(6)
   };
 
   // prologue: knots N-1 and N-2 into the two slots
