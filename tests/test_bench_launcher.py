@@ -1,11 +1,13 @@
 """bench.py's rank launcher and multi-rank plumbing, on CPU (gloo, world size 2): rank -> device map and
 environment, the refusal of a --gpus / WORLD_SIZE mismatch, and -- through `--dry-run`, which runs everything
 of the multi-rank path except the solver -- rendezvous, MAX-reduced region time, the final gather through
-sharding.gather_results and `n_gpus` in the JSON line."""
+sharding.gather_results and `n_gpus` in the JSON line; both scaling modes and both workloads through the same
+dry run; and the supervisor: a rank that dies before the rendezvous ends the job promptly instead of hanging it."""
 import json
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -51,3 +53,58 @@ def test_world_size_mismatch_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def _dry(*flags, timeout=300):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", *flags], env=_clean_env(),
+                         capture_output=True, text=True, timeout=timeout)
+    return out
+
+
+def test_dry_run_strong_scaling_splits_one_global_batch():
+    out = _dry("--gpus", "2", "--scaling", "strong", "--batch", "4097")
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["global_batch"] == 4097 and d["batch_rank0"] == 2049
+    assert d["sum_of_rank_batches"] == 4097  # contiguous shards cover the global batch exactly once
+
+
+def test_dry_run_weak_scaling_and_drone_defaults():
+    out = _dry("--gpus", "2")
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["batch_rank0"] == 4096 and d["global_batch"] == 8192 and d["sum_of_rank_batches"] == 8192
+    out = _dry("--gpus", "2", "--workload", "drone400")
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    # BASELINE config 5: 8192 trajectories in all, strong scaling by default (1024 per GPU on 8)
+    assert d["workload"] == "drone400" and d["scaling"] == "strong" and d["global_batch"] == 8192 and d["batch_rank0"] == 4096
+    a = bench.parse_args(["--workload", "drone400"])
+    assert (a.batch, a.horizon, a.scaling) == (8192, 400, "strong")
+    a = bench.parse_args([])
+    assert (a.batch, a.horizon, a.scaling, a.repeats) == (4096, 200, "weak", 10)
+
+
+def test_rank_dying_before_rendezvous_ends_the_job_promptly():
+    """Rank 1 exits 3 before init_process_group: rank 0 would wait in the rendezvous; the supervisor must take it
+    down and return the failure, well inside the rendezvous timeout."""
+    t0 = time.monotonic()
+    out = _dry("--gpus", "2", "--dry-run-fail-rank", "1", timeout=120)
+    dt = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-1000:])
+    assert dt < 60, dt
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]  # no result line from a failed job
+
+
+def test_supervisor_deadline_kills_stuck_ranks():
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"]) for _ in range(2)]
+    t0 = time.monotonic()
+    rc = bench.supervise(procs, deadline_s=1.0)
+    assert rc == 124 and time.monotonic() - t0 < 30
+    assert all(p.poll() is not None for p in procs)
+
+
+def test_lib_override_is_refused_without_the_flag(tmp_path):
+    env = _clean_env()
+    env["TOLG_HIP_LIB"] = str(tmp_path / "other.so")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "--allow-lib-override" in (out.stderr + out.stdout)

@@ -62,6 +62,29 @@ def test_fused_equals_split_se3(B, N):
     assert (keep["status"] == 0).all() and (keep["iters"] == 6).all()
 
 
+@pytest.mark.parametrize("B,N", [(8, 400), (4, 955)])
+def test_fused_long_horizons(B, N):
+    """The fused launch has no horizon limit (round 2 fell back to the split schedule beyond N = 313: its cost table
+    lived in LDS).  N = 400 is path_se3_spiral_static_velocity's horizon, N = 955 the reference's HEAD benchmark
+    problem (benchmark_SE3_tracking.py:49-58).  The auto schedule must really take the fused launch: no separate
+    linearisation launch is timed."""
+    prob, x0_q, x0_xi, us0 = workloads.se3_tracking(B, N=N)
+    keep, rs = _both(prob, x0_q, x0_xi, us0, 4, tol_grad_norm=0.0, tol_d_norm=0.0)
+    _assert_same(keep, rs)
+    assert (keep["status"] == 0).all() and (keep["iters"] == 4).all()
+    solver = BatchedTrackingILQR(prob, B)
+    dev = torch.device("cuda")
+    solver.solve_begin(torch.as_tensor(x0_q, device=dev), torch.as_tensor(x0_xi, device=dev), torch.as_tensor(us0, device=dev),
+                       mode="ms", n_iterations=3, tol_grad_norm=0.0, tol_d_norm=0.0)
+    solver.enable_timing(True)
+    solver.solve_iterate(3)
+    torch.cuda.synchronize()
+    ms_b, ms_r, ms_l, n_b = solver.kernel_time(reset=True)
+    solver.enable_timing(False)
+    solver.solve_end()
+    assert n_b == 3 and ms_r > 0.0 and ms_l == 0.0
+
+
 def test_fused_equals_split_drone_and_oracle():
     """m = 4, gravity block (the optional record field), against the oracle as well."""
     B, N, K = 9, 70, 8

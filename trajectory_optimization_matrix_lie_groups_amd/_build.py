@@ -1,24 +1,63 @@
 """In-tree build of the HIP extension (hipcc cross-compiles gfx950 without a GPU)."""
+import glob
+import hashlib
+import json
 import os
 import shutil
 import subprocess
+import time
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "csrc", "tolg_kernels.hip")
-_DEPS = [_SRC, os.path.join(_HERE, "csrc", "tolg_lie.h"), os.path.join(os.path.dirname(_HERE), "include", "tolg.h")]
 _SO = os.path.join(_HERE, "libtolg_hip.so")
+_INFO = os.path.join(_HERE, "_build_info.json")
+
+
+def _deps():
+    """Every file the library is compiled from: the kernel source, the headers beside it, the C ABI header."""
+    return [_SRC] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(os.path.dirname(_HERE), "include", "tolg.h")]
 
 
 def lib_path():
-    """The in-tree library; TOLG_HIP_LIB points at another build of the same ABI (A/B timing runs)."""
+    """The in-tree library; TOLG_HIP_LIB points at another build of the same ABI (A/B timing runs; bench.py
+    refuses it unless asked, and reports it when it is used)."""
     return os.environ.get("TOLG_HIP_LIB") or _SO
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources in `_deps()` as they are on disk now."""
+    h = hashlib.sha256()
+    for p in _deps():
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_info():
+    """What `build_extension` recorded beside the library: source hash, git head, time (the GPU box gets the
+    library and this file, not the .git directory)."""
+    try:
+        return json.load(open(_INFO))
+    except Exception:
+        return {}
 
 
 def _stale():
     if not os.path.exists(_SO):
         return True
     t = os.path.getmtime(_SO)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _DEPS)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
+
+
+def _git_head():
+    try:
+        root = os.path.dirname(_HERE)
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "trajectory_optimization_matrix_lie_groups_amd/csrc",
+                                         "include"], stderr=subprocess.DEVNULL).decode().strip()
+        return head + ("+uncommitted-source-changes" if dirty else "")
+    except Exception:
+        return None
 
 
 def build_extension(force=False, verbose=False, extra_flags=()):
@@ -32,4 +71,7 @@ def build_extension(force=False, verbose=False, extra_flags=()):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(_INFO, "w") as f:
+        json.dump({"source_sha256_16": source_hash(), "git_head": _git_head(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%S"),
+                   "flags": list(extra_flags)}, f)
     return _SO

@@ -2445,11 +2445,13 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
   // One LDS object, carved by hand: the input ring first -- the LDS-DMA base register M0 is used with its
   // classic 16-bit range, so every DMA destination stays below 64 KB -- then the state ring, then the counters.
   static_assert(RL_DEPTH * IN::SLOT <= 65536 && IN::SLOT % 16 == 0, "LDS-DMA destinations must stay below 64 KB");
-  // ... and, in dynamic LDS behind it, the stage costs [N + 1][16]: the helper that finishes last sums the costs of
-  // the workgroup's trajectories in knot order and does the per-iteration bookkeeping (k_reduce's job in the split
-  // schedule).  rl_lds_bytes() is the total; the host falls back to the split schedule when it exceeds the CU's LDS.
+  // ... and the partial cost sums [helper][knot of a pass][trajectory]: every helper lane adds up the stage costs of
+  // the knots it linearises (one knot of every second pass: a fixed order), the helper that finishes last adds the
+  // eight partial sums of each trajectory in a fixed order and does the per-iteration bookkeeping (k_reduce's job in
+  // the split schedule).  No table over the horizon: the launch has no horizon limit (round 2 kept [N + 1][16] stage
+  // costs in dynamic LDS and fell back to the split schedule beyond N = 313 for m = 6).
   __shared__ __attribute__((aligned(16))) char lds[rl_static_lds<M>()];
-  extern __shared__ __attribute__((aligned(16))) double lcost[];  // [N + 1][16], sized at launch
+  __shared__ double lpart[RL_NH][4][16];
   char (*inring)[IN::SLOT] = reinterpret_cast<char (*)[IN::SLOT]>(lds);
   double (*ring)[RL_PAIRS * 32] = reinterpret_cast<double (*)[RL_PAIRS * 32]>(lds + RL_DEPTH * IN::SLOT);
   int* sync = reinterpret_cast<int*>(lds + RL_DEPTH * IN::SLOT + RL_RING * RL_PAIRS * 256);
@@ -2604,10 +2606,12 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const int ch = c * 64 + lane;
-        if (ch < 13 * 8) rl_dma16(xs + (size_t)(ch >> 3) * sB + (ch & 7) * 16, dst + IN::GAINS + c * 1024);
+        // (pieces of trajectories past the batch re-read piece 0 of the row: a short last workgroup must not read
+        // beyond the end of the arrays)
+        if (ch < 13 * 8) rl_dma16(xs + (size_t)(ch >> 3) * sB + (((ch & 7) * 2 < ntraj) ? (ch & 7) : 0) * 16, dst + IN::GAINS + c * 1024);
       }
       const char* us = reinterpret_cast<const char*>(P.cur_u + uStride * k + b0);
-      if (lane < M * 8) rl_dma16(us + (size_t)(lane >> 3) * sB + (lane & 7) * 16, dst + IN::GAINS + IN::STATE);
+      if (lane < M * 8) rl_dma16(us + (size_t)(lane >> 3) * sB + (((lane & 7) * 2 < ntraj) ? (lane & 7) : 0) * 16, dst + IN::GAINS + IN::STATE);
     };
     // Inputs: knot k may be issued once step k - RL_DEPTH has completed; a knot is published once its DMAs have
     // retired -- the memory queue retires in order, so "at most n knots still outstanding" is a counted s_waitcnt
@@ -2673,6 +2677,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
   const bool mine = b < P.Bp && P.active[b < P.Bp ? b : 0] != 0;
   const int ngroups = (N + 1 + 3) / 4;
   int done = 0;
+  double jpart = 0.0;  // stage costs of this lane's knots (kk, kk + 8, ... of helper 0; kk + 4, kk + 12, ... of helper 1)
 #ifdef TOLG_STAMPS
   unsigned long long hs_wait = 0, hs_work = 0, hs_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -2705,24 +2710,33 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
       }
       if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
       // the terminal knot (in the last group only) goes separately: see lin_knot's TERM
-      if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
-      if (4 * g + 3 >= N && i == N) lin_knot<M, true, 1>(P, C, i, b, 1, S, u, [&]() { return S; }, &lcost[i * 16 + tt]);
+      double lc = 0.0;
+      if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
+      if (4 * g + 3 >= N && i == N) lin_knot<M, true, 1>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
+      jpart += lc;
     }
     done++;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every ring read of this pass has returned
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) vs[2 + h] = done;
   }
-  // ---- the helper that finishes last: trajectory costs in knot order (the summation order of k_reduce), then the
-  // on_iteration bookkeeping of traopt_controller.py:2621-2626.  LDS operations of a wave execute in order, so the
-  // other helper's cost writes precede its arrival on the counter.
+  // ---- the helper that finishes last: trajectory costs from the eight partial sums (fixed order: deterministic; the
+  // order differs from k_reduce's knot order, i.e. fused and split schedules agree to rounding, not to the bit), then
+  // the on_iteration bookkeeping of traopt_controller.py:2621-2626.  LDS operations of a wave execute in order, so
+  // the other helper's writes precede its arrival on the counter.
+  lpart[h][kk][tt] = jpart;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
   int last = 0;
   if (lane == 0) last = __hip_atomic_fetch_add(&sync[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == RL_NH - 1;
   last = __builtin_amdgcn_readfirstlane(last);
   if (last && mine && kk == 0) {
     asm volatile("" ::: "memory");
     double J = 0;
-    for (int i = 0; i <= N; i++) J += lcost[i * 16 + tt];
+#pragma unroll
+    for (int hh = 0; hh < RL_NH; hh++)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) J += lpart[hh][k4][tt];
     P.Jc[b] = J;
     P.dn[b] = 0.0;  // closed by construction
     if (b < P.B) {
@@ -3341,10 +3355,6 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) lds = 65536;
     h->lds_per_block = lds;
-    // the fused kernel's dynamic LDS (cost table) comes on top of ~120 KB of static rings
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_lin<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_lin<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipGetLastError();
   }
   Consts& c = h->hc;
   memset(&c, 0, sizeof c);
@@ -3578,13 +3588,12 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
-    const size_t dyn_lds = (size_t)(P.N + 1) * 16 * sizeof(double);
     if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
-        opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + dyn_lds <= (size_t)h->lds_per_block) {
+        opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block) {
       // accept-always nonlinear rollout and the re-linearisation of the new trajectory in one launch
       {
         Timed t(h, st, 1);
-        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), dyn_lds, st, P, it);
+        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P, it);
         LAUNCH_CHECK();
         h->rec_closed = 1;  // its records carry no defect field (zero by construction): K2 reads zeros instead
       }

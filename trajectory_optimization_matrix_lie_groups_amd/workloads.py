@@ -74,11 +74,28 @@ def perturbed_batch(q0, xi0, B, scale_pose, scale_twist, seed=SEED):
     return x0_q, x0_xi
 
 
+def _extend_reference(q_ref, xi_ref, dt, N):
+    """Horizons beyond the stored 201 knots of path_se3_generate_sine_2 (the reference's longer problems --
+    path_se3_spiral_static_velocity N = 400, the HEAD benchmark problem N = 955, benchmark_SE3_tracking.py:49-58 --
+    are not among the stored data files): the path is continued the way the reference generates its own,
+    q_{i+1} = q_i Exp(xi_i dt) with a smooth twist profile (main_SE3ddp_tracking_exact_ms.py:52-85), starting from
+    the last stored knot.  Synthetic data of the reference's shape, not the reference's path."""
+    n0 = q_ref.shape[0]
+    q = np.empty((N + 1, 4, 4)); xi = np.empty((N + 1, 6))
+    q[:n0] = q_ref; xi[:n0] = xi_ref
+    for i in range(n0 - 1, N):
+        s = float(i - (n0 - 1))
+        xi[i + 1] = xi_ref[-1] + np.array([0.4 * np.sin(s / 40.0), 0.2 * np.sin(s / 55.0), 0.3 * np.sin(s / 70.0),
+                                           0.5 * np.sin(s / 45.0), 0.4 * np.sin(s / 60.0), 0.3 * np.sin(s / 80.0)])
+        q[i + 1] = q[i] @ _se3_exp(xi[i] * dt)
+    return q, xi
+
+
 def se3_tracking(B, N=200, R_scale=1e-5, seed=SEED):
     """BASELINE metric / config 3: SE3 exact tracking, N=200, dt=0.05 on path_se3_generate_sine_2."""
     q_ref, xi_ref, dt = load_reference("se3_sine2_n200")
     if N + 1 > q_ref.shape[0]:
-        raise ValueError("path_se3_generate_sine_2 has %d knots: horizon N must be <= %d" % (q_ref.shape[0], q_ref.shape[0] - 1))
+        q_ref, xi_ref = _extend_reference(q_ref, xi_ref, dt, N)
     q_ref, xi_ref = q_ref[: N + 1], xi_ref[: N + 1]
     Q = np.diag([25.0, 25, 25, 10, 10, 10, 1, 1, 1, 1, 1, 1])
     prob = TrackingProblem("se3", inertia(), dt, Q, np.eye(6) * R_scale, 1.5 * Q, q_ref, xi_ref)
