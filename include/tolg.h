@@ -190,6 +190,17 @@ void tolg_enable_timing(tolg_handle_t h, int32_t on);
 
 const char* tolg_version(void);
 
+/* Diagnostic (no reference counterpart): the series forms of the Lie primitives (csrc/tolg_lie.h: se3_exp_fast,
+ * se3_log_fast, so3_coef_fast, ljacinv_coef_fast, so3_exp_fast) evaluated one lane per argument set, under the
+ * wave-shared gates their callers build -- so that arguments on both sides of every tier / domain boundary share a
+ * wavefront -- for the parity test of those forms against a long-double reference (tests/test_gpu_series.py).
+ *   in : d_args [n][8] = rotation vector w (3), translation part v (3), th2 of a second (step) rotation, mode
+ *        (0: every function under its own gate, 1: one gate for all, built as lin_knot builds it)
+ *   out: d_out [n][24] = so3_coef_fast a b c1 c2 c3 | ljacinv_coef_fast | se3_exp_fast q(4) t(3) |
+ *        se3_log_fast(se3_exp(w, v)) w(3) v(3) | so3_exp_fast(w) q(4) | so3_coef_fast(th2_step).a
+ * n must be a multiple of 64. */
+int tolg_selftest_series(int32_t n, const double* d_args, double* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ class Options(C.Structure):
 _lib = None
 SYMBOLS = ["tolg_workspace_bytes", "tolg_create", "tolg_destroy", "tolg_solve_batch", "tolg_solve_begin",
            "tolg_solve_iterate", "tolg_solve_end", "tolg_solve_peek", "tolg_solve_active_count", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
-           "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version"]
+           "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version", "tolg_selftest_series"]
 
 
 def load():
@@ -77,6 +77,8 @@ def load():
     lib.tolg_enable_timing.argtypes = [vp, C.c_int32]
     lib.tolg_version.restype = C.c_char_p
     lib.tolg_version.argtypes = []
+    lib.tolg_selftest_series.restype = C.c_int
+    lib.tolg_selftest_series.argtypes = [C.c_int32, dp, dp, vp]
     _lib = lib
     return lib
 

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // Rt = 2 D^-1 R D^-1 (lanes that hold a column of Mt), the update masks of the factorisation
   double bu[M], ibu[M];
 #pragma unroll
-  for (int u = 0; u < M; u++) { bu[u] = fu_entry<M>(C, urow<M>(u) - 6, u); ibu[u] = 1.0 / bu[u]; }
+  for (int u = 0; u < M; u++) { bu[u] = fu_entry<M>(*P.c, urow<M>(u) - 6, u); ibu[u] = 1.0 / bu[u]; }  // generic pointer: note at DConsts
   double kBW[6], Rt[M], wm[M];
 #pragma unroll
   for (int r = 0; r < 6; r++) kBW[r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : 0.0;

@@ -50,6 +50,12 @@ struct Consts {
 // that uniform reads become scalar loads (lgkmcnt) and never queue behind in-flight record
 // prefetches on vmcnt.  Cold kernels keep the generic pointer: with a few hundred invariant scalar
 // loads hoisted out of their knot loops they would only spill SGPRs.
+// F_u's constants (Bt / Bb: fu_entry, dynk_load) are read through the GENERIC pointer everywhere, once, ahead of
+// the knot loops, and pinned in vector registers / LDS: reading them through this view inside k_rollout_eval's knot
+// loop gave wrong costs and memory-aperture faults in round 2 (profiles/r02_as4_cold_kernel_bisect.md; the ISA of
+// the failing build was re-read in round 3 -- scalar tuple s[8:23] loaded ahead of the loop, copied to AGPRs by
+// v_accvgpr_write inside it, nothing found that overwrites it -- and the cause is still open), so no hot kernel
+// depends on that construct any more.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(4))) Consts DConsts;
 #else
@@ -251,7 +257,7 @@ TOLG_DEV State dyn_f(const CT& C, const State& S, const double (&u)[M]) {
   if constexpr (M == 6) bot = bot + v3(u[3], u[4], u[5]);
   else bot = bot + v3(0, 0, u[3]);
   if (dj) {
-    F.w = S.w + v3(C.Bt[0] * top.x, C.Bt[4] * top.y, C.Bt[8] * top.z);  // Bt = Ib^-1 dt
+    F.w = S.w + v3(C.Bt[0] * top.x, C.Bt[4] * top.y, C.Bt[8] * top.z);  // Bt = Ib^-1 dt (K1 / probe: no knot loop around it)
     F.v = S.v + dt * v3(C.Jvinv[0] * bot.x, C.Jvinv[4] * bot.y, C.Jvinv[8] * bot.z);
   } else {
     F.w = S.w + dt * mv33(C.Ibinv, top);
@@ -1649,16 +1655,16 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
   if (g == 0) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      KC[j][KC_BW + r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : (j < M) ? fu_entry<M>(C, r, j) : 0.0;  // B[6+r][j]
+      KC[j][KC_BW + r] = (j >= 6 && j < 12) ? 2.0 * C.W2[6 * r + (j - 6)] : (j < M) ? fu_entry<M>(*P.c, r, j) : 0.0;  // B[6+r][j]
     }
 #pragma unroll
     for (int u = 0; u < 6; u++) {
       KC[j][KC_RB + u] = (u < M && j < M) ? 2.0 * C.R[(u < M ? u : 0) * M + j]
-                         : (u < M && j >= 6 && j < 12) ? fu_entry<M>(C, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
+                         : (u < M && j >= 6 && j < 12) ? fu_entry<M>(*P.c, j - 6, u < M ? u : 0) : 0.0;  // B[j][u]
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = C.Bt[k]; KC[j][KC_BB + k] = C.Bb[k]; }
-    KC[j][KC_BD] = (j < M) ? fu_entry<M>(C, j < 6 ? j : 0, j) : 0.0;
+    for (int k = 0; k < 9; k++) { KC[j][KC_BT + k] = P.c->Bt[k]; KC[j][KC_BB + k] = P.c->Bb[k]; }
+    KC[j][KC_BD] = (j < M) ? fu_entry<M>(*P.c, j < 6 ? j : 0, j) : 0.0;
   }
   if (lane < 12) TRZ[lane] = 0.0;
   __builtin_amdgcn_wave_barrier();
@@ -2280,7 +2286,7 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   } else {
     Sn = load_state_b(mkbuf(P.cand + (size_t)13 * P.Bp * i0, 13 * sB), vb, sB);
   }
-  const DynK DK = dynk_load(C);
+  const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
 #ifdef TOLG_STAMPS
   RStamps ST;
   for (int k = 0; k < 8; k++) ST.acc[k] = 0;
@@ -2489,7 +2495,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) vs[0] = 0;
-    const DynK DK = dynk_load(C);
+    const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
     State Sa = Sn, Sb = Sn;
     double un[M];
 #ifdef TOLG_STAMPS
@@ -2636,7 +2642,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     // i + 1.  Four lanes per trajectory, as in wave 0 (same lane -> trajectory map, lane 0 of a quad writes).
     const int tt = lane >> 2;
     const bool writer = (lane & 3) == 0;
-    const DynK DK = dynk_load(C);
+    const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
     State S = rl_in_state<M>(inring[0], tt);  // x^_0 = x_0
 #ifdef TOLG_STAMPS
     unsigned long long pw[3] = {0, 0, 0}, pw_t = __builtin_amdgcn_s_memtime();
@@ -3183,6 +3189,39 @@ __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restri
   }
 }
 // number of trajectories still being iterated (integer atomics: order-independent)
+// diagnostic kernel of tolg_selftest_series (include/tolg.h): one lane per argument set
+__global__ __launch_bounds__(64) void k_selftest_series(int n, const double* __restrict__ args, double* __restrict__ out) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n) return;
+  const double* a = args + 8 * (size_t)t;
+  const V3 w = v3(a[0], a[1], a[2]), v = v3(a[3], a[4], a[5]);
+  const double th2s = a[6];
+  const bool shared = a[7] != 0.0;
+  const double th2 = dot(w, w);
+  const Pose Xc = se3_exp(w, v);  // closed form: the argument of the Log test
+  const double y = quat_vec2(Xc.q);
+  // the gate lin_knot builds: tracking-error Log and the series at its angle, plus the step rotation
+  const SeriesGate gs = series_gate(log_small(y) && coef_small(th2s), log_dom(y) && exp_dom(th2s));
+  double* o = out + 24 * (size_t)t;
+  V3 lw, lv;
+  if (shared) se3_log_fast(Xc, lw, lv, gs);
+  else se3_log_fast(Xc, lw, lv);
+  const double th2l = dot(lw, lw);  // the Log's angle: what lin_knot feeds the coefficient series with
+  const SO3Coef k = shared ? so3_coef_fast(th2l, true, gs) : so3_coef_fast(th2, true);
+  o[0] = k.a; o[1] = k.b; o[2] = k.c1; o[3] = k.c2; o[4] = k.c3;
+  o[5] = shared ? ljacinv_coef_fast(th2l, gs) : ljacinv_coef_fast(th2);
+  // Exp under its own gate (the rollout builds it from exp_small / exp_dom of the same rotation)
+  const Pose E = se3_exp_fast(w, v);
+  o[6] = E.q.x; o[7] = E.q.y; o[8] = E.q.z; o[9] = E.q.w; o[10] = E.t.x; o[11] = E.t.y; o[12] = E.t.z;
+  o[13] = lw.x; o[14] = lw.y; o[15] = lw.z; o[16] = lv.x; o[17] = lv.y; o[18] = lv.z;
+  // the step rotation about w's axis with angle^2 th2s, under the shared gate (so3_exp_fast + coefficient a)
+  const double sc = (th2 > 0.0) ? sqrt(th2s / th2) : 0.0;
+  const V3 ws = sc * w;
+  const Q4 q = shared ? so3_exp_fast(ws, gs) : so3_exp_fast(ws);
+  o[19] = q.x; o[20] = q.y; o[21] = q.z; o[22] = q.w;
+  o[23] = (shared ? so3_coef_fast(dot(ws, ws), true, gs) : so3_coef_fast(dot(ws, ws), true)).a;
+}
+
 __global__ void k_active_count(Params P, int* __restrict__ out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool a = b < P.B && P.active[b] != 0;
@@ -3319,7 +3358,7 @@ extern "C" size_t tolg_workspace_bytes(const tolg_problem* prob, int32_t max_bat
   return carve_all(prob, Bp, nullptr, nullptr, nullptr);
 }
 
-extern "C" const char* tolg_version(void) { return "tolg-hip 0.1 (gfx950)"; }
+extern "C" const char* tolg_version(void) { return "tolg-hip 0.3 (gfx950)"; }
 
 #define LAUNCH_CHECK()                                         \
   do {                                                         \
@@ -3816,6 +3855,13 @@ extern "C" int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear,
   size_t n = (size_t)(P.N + 1) * P.Bp;
   hipLaunchKernelGGL(k_unpack_traj, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, P.cand, P.cand_u, d_xs_q_new,
                      d_xs_xi_new, d_us_new);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tolg_selftest_series(int32_t n, const double* d_args, double* d_out, void* stream) {
+  if (n < 64 || (n % 64) != 0 || !d_args || !d_out) return TOLG_E_ARG;
+  hipLaunchKernelGGL(k_selftest_series, dim3(n / 64), dim3(64), 0, static_cast<hipStream_t>(stream), n, d_args, d_out);
   LAUNCH_CHECK();
   return 0;
 }

@@ -220,15 +220,38 @@ TOLG_DEV SeriesGate series_gate(bool small, bool dom) {
 }
 // Per-lane predicates of the four argument kinds.  A gate built from log_small / log_dom of y = |q_v|^2 also
 // covers the evaluations at the resulting angle th2 = (2 asin sqrt y)^2: y < 1e-3 gives th2 < 4.002e-3 (inside
-// coef_small and ljinv_small), y < 1/16 gives th2 < 0.2554 (inside coef_dom and ljinv_dom).
-TOLG_DEV bool exp_small(double th2) { return th2 < 0.04; }                   // 5 / 6 / 6 terms reach 1e-17
-TOLG_DEV bool exp_dom(double th2) { return th2 > TOLG_EPS && th2 < 1.0; }
-TOLG_DEV bool log_small(double y) { return y < 1e-3; }                       // 6 / 5 terms
-TOLG_DEV bool log_dom(double y) { return y < 0.0625; }
-TOLG_DEV bool coef_small(double th2) { return th2 < 0.04; }                  // 6 terms of each
-TOLG_DEV bool coef_dom(double th2) { return th2 < 1.0; }
-TOLG_DEV bool ljinv_small(double th2) { return th2 < 0.01; }                 // 5 terms
-TOLG_DEV bool ljinv_dom(double th2) { return th2 < 0.26; }
+// coef_small and ljinv_small), y < 1/16 gives th2 < 0.2554 (inside coef_dom and ljinv_dom).  horner2 trusts the
+// gate (any_long false = every lane small for EVERY series evaluated under it), so the thresholds are tied together
+// at compile time: callers share one gate between Exp and coefficient series in both directions (roll_step: an
+// exp_small gate over the (th - sin th)/th^3 series; lin_knot: a coef_small gate over so3_exp_fast), and between
+// Log and the series evaluated at the Log's angle.
+constexpr double kExpSmall = 0.04, kExpDomHi = 1.0;        // 5 / 6 / 6 terms reach 1e-17
+constexpr double kLogSmallY = 1e-3, kLogDomY = 0.0625;     // 6 / 5 terms
+constexpr double kCoefSmall = 0.04, kCoefDom = 1.0;        // 6 terms of each
+constexpr double kLjinvSmall = 0.01, kLjinvDom = 0.26;     // 5 terms
+// upper bound of (2 asin x)^2: asin x = x + x^3/6 + 3x^5/40 + 15x^7/336 + ..., coefficients decreasing, so the
+// tail after the x^7 term is below (35/1152) x^9 / (1 - x^2)
+constexpr double angle2_ub(double x) {
+  const double x2 = x * x;
+  const double a = x * (1.0 + x2 * (1.0 / 6 + x2 * (3.0 / 40 + x2 * (15.0 / 336)))) + (35.0 / 1152) * x2 * x2 * x2 * x2 * x / (1.0 - x2);
+  return 4.0 * a * a;
+}
+constexpr double kLogSmallX = 0.0316228, kLogDomX = 0.25;  // >= sqrt of the y thresholds
+static_assert(kLogSmallX * kLogSmallX >= kLogSmallY && kLogDomX * kLogDomX >= kLogDomY, "x bounds of the Log thresholds");
+static_assert(kExpSmall == kCoefSmall, "one gate serves Exp and coefficient series in both directions");
+static_assert(kExpDomHi <= kCoefDom, "an exp_dom gate covers so3_coef_fast at the same angle");
+static_assert(angle2_ub(kLogSmallX) <= kLjinvSmall && angle2_ub(kLogSmallX) <= kCoefSmall,
+              "a log_small gate covers the series evaluated at the Log's angle");
+static_assert(angle2_ub(kLogDomX) <= kLjinvDom && angle2_ub(kLogDomX) <= kCoefDom,
+              "a log_dom gate covers the domains of the series evaluated at the Log's angle");
+TOLG_DEV bool exp_small(double th2) { return th2 < kExpSmall; }
+TOLG_DEV bool exp_dom(double th2) { return th2 > TOLG_EPS && th2 < kExpDomHi; }
+TOLG_DEV bool log_small(double y) { return y < kLogSmallY; }
+TOLG_DEV bool log_dom(double y) { return y < kLogDomY; }
+TOLG_DEV bool coef_small(double th2) { return th2 < kCoefSmall; }
+TOLG_DEV bool coef_dom(double th2) { return th2 < kCoefDom; }
+TOLG_DEV bool ljinv_small(double th2) { return th2 < kLjinvSmall; }
+TOLG_DEV bool ljinv_dom(double th2) { return th2 < kLjinvDom; }
 // r y + c as one three-address instruction.  Left to itself the compiler turns a Horner step whose coefficient
 // lives in a register across the knot loop into v_mov_b64 + v_fmac_f64 (the two-address form clobbers its addend),
 // i.e. two issue slots of a wave that is issue-bound at one fp64 instruction per ~5 cycles.
