@@ -96,7 +96,7 @@ struct Params {
   const double* al_lambda;  // [B][N][2m]
   const double* al_imu;     // [B][N][2m] diagonal of I_mu
 };
-enum { NSLOT = 8, NALPHA_MS = 20, NALPHA_SS = 13 };
+enum { NSLOT = 12, NALPHA_MS = 20, NALPHA_SS = 13 };  // slots: the widest stage (the first alpha goes straight to the candidate arrays)
 
 // every array is knot-major [knot][field][Bp]: one knot of one field is a contiguous run over the batch
 #define SIDX(c, i, b) ((((size_t)(i)) * 13 + (size_t)(c)) * (size_t)P.Bp + (size_t)(b))
@@ -2124,10 +2124,13 @@ struct RStamps { unsigned long long acc[8], t; };
 // STORE: the writer lane stores u^_i and x^_{i+1} to the candidate arrays; otherwise the caller takes them
 // (un_out and the return value) -- the fused rollout hands them to its linearisation wavefronts through LDS.
 // load_in(R): requests this step's gains and controls (from HBM, or from the LDS input ring of the fused kernel).
+// what the line-search evaluation and the expected-cost-change kernels need from inside a step
+template <int M>
+struct RollProbe { double e[12], du[M]; State Fn; };
 template <int M, bool LINEAR, bool ALPHA1, int PK, bool STORE, class CT, class LoadFn>
 TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
                          unsigned sB, double alpha, const State& So, const State& Sn, double (&un_out)[M],
-                         LoadFn load_in RST_PARAM) {
+                         LoadFn load_in, RollProbe<M>* probe RST_PARAM) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp;
   RSTAMP(0)
   RollIn<M> R;
@@ -2164,11 +2167,18 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   if constexpr (M == 6) { du[4] = quad_bcast<2>(mine[0]); du[5] = quad_bcast<2>(mine[1]); }
 #pragma unroll
   for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
+  if (probe) {
+#pragma unroll
+    for (int a = 0; a < 12; a++) probe->e[a] = e[a];
+#pragma unroll
+    for (int a = 0; a < M; a++) probe->du[a] = du[a];
+  }
   RSTAMP(3)
   State Nx;
   if constexpr (!LINEAR) {
     if (DK.diag) dyn_twist_k<M, CT, PK>(DK, C, Sn, un, Fn);
     else Fn = dyn_f<M, CT, PK>(C, Sn, un);
+    if (probe) probe->Fn = Fn;
     if constexpr (ALPHA1) {
       // alpha = 1 (and single shooting): the factors of :2713-2716 are the identity and zero up to rounding
       // (see the note at the record layout), the step is x^_{i+1} = f(x^_i, u^_i)
@@ -2298,12 +2308,12 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
     if (i + 1 < i1) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
     Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un_,
-                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R); } RST_ARG);
+                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
     if (i + 1 >= i1) break;
     if (i + 2 < i1) Sa = roll_load_state(P, i + 2, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
     Sn = roll_step<M, LINEAR, ALPHA1, PK, true>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un_,
-                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i + 1, b, q, vb, sB, R); } RST_ARG);
+                                                [&](RollIn<M>& R) { roll_load<M, ALPHA1>(P, i + 1, b, q, vb, sB, R); }, nullptr RST_ARG);
   }
 #ifdef TOLG_STAMPS
   if (blockIdx.x == 5 && threadIdx.x == 0 && P.alpha_hist) { for (int k = 0; k < 8; k++) P.alpha_hist[(size_t)80 * P.max_iter + k] = (double)ST.acc[k]; }
@@ -2812,9 +2822,11 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
   return l;
 }
 
-// one thread per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm
+// one thread per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm -- the form of the
+// wide stages (many alphas per trajectory: 64 waves per alpha keep a 12-alpha stage within one wave per SIMD; the
+// quad form below takes four times the waves and runs the first, one-alpha stage in 0.68 instead of 1.15 ms)
 template <int M, bool MS, bool LINEAR>
-__global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslots) {
+__global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nslots) {
   const Consts& C = *P.c;
   const int b = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   if (b >= P.Bp || slot >= nslots) return;
@@ -2902,26 +2914,159 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
   P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
 }
 
-// MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
-// _expected_cost_change (:2756-2769), _update_defect_weight (:2774-2788)
+// stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738), this lane's share: the four lanes of a trajectory
+// split the rows of the weight matrices (lane q: rows q and q + 4), every lane keeps a partial sum over the whole
+// horizon and the quad adds its four partials once, at the end.  The lane's weight rows are read once, ahead of the
+// knot loop (QuadW): inside it they were ~30 vector loads per knot on the sequential chain.
 template <int M>
+struct QuadW { double w1[2][6], w2[2][6], r[2][M]; };
+template <int M>
+TOLG_DEV QuadW<M> quadw_load(const Consts& C, int q, bool term) {
+  QuadW<M> W;
+  const bool so3 = so3_family(C.kind);  // the SO3 terminal cost is weighted with Q (App. C-Q3)
+  const double* W1 = (term && !so3) ? C.P1 : C.W1;
+  const double* W2 = (term && !so3) ? C.P2 : C.W2;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int a = q + 4 * h, a6 = a < 6 ? a : 0, aM = a < M ? a : 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { W.w1[h][k] = (a < 6) ? W1[6 * a6 + k] : 0.0; W.w2[h][k] = (a < 6) ? W2[6 * a6 + k] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < M; k++) W.r[h][k] = (!term && a < M) ? C.R[aM * M + k] : 0.0;
+  }
+  return W;
+}
+template <int M>
+TOLG_DEV double knot_cost_q(const Params& P, const QuadW<M>& W, int i, int b, int q, const State& S, const double (&u)[M], bool term) {
+  const double* r = P.ref + 13 * (size_t)i;
+  Pose Xr;
+  Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
+  Xr.t = v3(r[4], r[5], r[6]);
+  V3 ew, ev;
+  se3_log_fast(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+  const double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
+  const double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
+  double l = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int a = q + 4 * h;  // rows q (every lane) and q + 4 (lanes 0, 1); rows past the matrix carry zero weights
+    double s1 = 0, s2 = 0, s3 = 0, ea = 0, va = 0, ua = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { s1 += W.w1[h][k] * e[k]; s2 += W.w2[h][k] * ve[k]; ea = (k == a) ? e[k] : ea; va = (k == a) ? ve[k] : va; }
+#pragma unroll
+    for (int k = 0; k < M; k++) { s3 += W.r[h][k] * u[k]; ua = (k == a) ? u[k] : ua; }
+    l += ea * s1 + va * s2 + ua * s3;
+    if (!term && P.al_lb && a < M) {
+      const int bs = b < P.B ? b : P.B - 1;
+      const double* lam = P.al_lambda + ((size_t)bs * P.N + i) * 2 * M;
+      const double* imu = P.al_imu + ((size_t)bs * P.N + i) * 2 * M;
+      const double g1 = P.al_lb[a] - ua, g2 = ua - P.al_ub[a];
+      l += lam[a] * g1 + lam[M + a] * g2 + 0.5 * (g1 * imu[a] * g1 + g2 * imu[M + a] * g2);
+    }
+  }
+  return l;
+}
+TOLG_DEV double quad_sum(double x) { return ((quad_bcast<0>(x) + quad_bcast<1>(x)) + quad_bcast<2>(x)) + quad_bcast<3>(x); }
+
+// four lanes per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm.  The step is
+// roll_step (the quad rollout of K3: gain product split by row pairs, series forms of Exp / Log); round 2 ran one
+// thread per (trajectory, slot) -- 64 waves at 4096 trajectories, ~1.15 ms per stage whatever the number of alphas
+// (profiles/r03_mid_kernel_stats_ss.csv) -- which made single shooting 4.7 ms per iteration.
+template <int M, bool MS, bool LINEAR, int PK>
+__global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslots, int direct) {
+  const Consts& C = *P.c;  // generic pointer (note at DConsts)
+  const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
+  int b = t >> 2;
+  const int q = t & 3;
+  const bool live = b < P.Bp;  // quads past the batch replay the last trajectory (DPP needs whole quads) and store nothing
+  if (!live) b = P.Bp - 1;
+  if (slot >= nslots || !P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
+  const bool writer = live && q == 0;
+  const int N = P.N, ai = a0 + slot;
+  const double alpha = ls_alpha_k(ai);
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp;
+  // direct: the one alpha of this stage writes straight into the candidate arrays (the first try, which most
+  // iterations accept: no slot, no copy); otherwise slot `slot`
+  double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
+  double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  if (writer) store_state_b(mkbuf(sx, 13 * sB), vb, sB, Sn);
+  const DynK DK = dynk_load(C);
+  const QuadW<M> QW = quadw_load<M>(C, q, false);
+  double J = 0, d2 = 0;
+  State So = roll_load_state(P, 0, vb, sB);
+#ifdef TOLG_STAMPS
+  RStamps ST;
+  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+  ST.t = __builtin_amdgcn_s_memtime();
+#endif
+  for (int i = 0; i < N; i++) {
+    State Sx = So;  // nominal state of knot i; knot i + 1 is requested before the step needs it
+    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
+    __builtin_amdgcn_sched_barrier(0);
+    double un[M];
+    RollProbe<M> pr;
+    // single shooting steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
+    const State Nx = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sx, Sn, un,
+                                                          [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, &pr RST_ARG);
+    J += knot_cost_q<M>(P, QW, i, b, q, Sn, un, false);
+    if constexpr (MS) {  // new defect Log(x^_{i+1}^-1 f_q(x^_i,u^_i)), f_xi - xi^_{i+1}
+      State Fn;
+      if constexpr (LINEAR) Fn = dyn_f_k<M, Consts, PK>(DK, C, Sn, un);
+      else Fn = pr.Fn;
+      V3 dw, dv;
+      se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+      V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
+      d2 += dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
+    }
+    if (writer) {
+      __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB);
+#pragma unroll
+      for (int a = 0; a < M; a++) bst(rSU, vb, a * sB, un[a]);
+      store_state_b(mkbuf(sx + stStride * (i + 1), 13 * sB), vb, sB, Nx);
+    }
+    Sn = Nx;
+  }
+  double uz[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) uz[a] = 0;
+  J += knot_cost_q<M>(P, quadw_load<M>(C, q, true), N, b, q, Sn, uz, true);
+  J = quad_sum(J);
+  if (writer) {
+    P.Jtrial[(size_t)b * 20 + ai] = J;
+    P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
+  }
+}
+
+// MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
+// _expected_cost_change (:2756-2769), _update_defect_weight (:2774-2788).  Four lanes per trajectory, the step is
+// roll_step's linear form (round 2: one thread per trajectory, 3.9 ms per call -- half of a merit-search iteration).
+template <int M, int PK>
 __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   const Consts& C = *P.c;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.Bp || !P.active[b]) return;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  int b = t >> 2;
+  const int q = t & 3;
+  const bool live = b < P.Bp;
+  if (!live) b = P.Bp - 1;
+  if (!P.active[b]) return;  // quad-uniform
+  const bool writer = live && q == 0;
   const int N = P.N;
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, gStride = (size_t)13 * M * P.Bp;
+  const size_t recStride = (size_t)P.recF * P.Bp;
   State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  const DynK DK = dynk_load(C);
   double c1 = 0, c2 = 0;
-  for (int i = 0; i <= N; i++) {
+  State So = roll_load_state(P, 0, vb, sB);
+#ifdef TOLG_STAMPS
+  RStamps ST;
+  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+  ST.t = __builtin_amdgcn_s_memtime();
+#endif
+  // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
+  auto state_terms = [&](int i, const double (&e)[12]) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
-    State So = load_state_b(mkbuf(P.cur + stStride * i, 13 * sB), vb, sB);
-    V3 ew, ev;
-    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
-    double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
-                    Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
-    // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
     const double* W2 = (i == N) ? C.P2 : C.W2;
 #pragma unroll
     for (int a = 0; a < 12; a++) c1 += bld(rR, REC_VR(b), FOFF(REC_LX + a)) * e[a];
@@ -2932,33 +3077,34 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
         c2 += e[a] * bld(rR, REC_VR(b), FOFF(REC_LXX + sym6(a, k))) * e[k];
         c2 += e[6 + a] * 2.0 * W2[6 * a + k] * e[6 + k];
       }
-    if (i == N) break;
-    __amdgpu_buffer_rsrc_t rG = mkbuf(P.GK + gStride * i, 13 * M * sB);
-    double du[M];
+  };
+  for (int i = 0; i < N; i++) {
+    State Sx = So;
+    So = roll_load_state(P, i + 1, vb, sB);  // knot N too: the terminal deviation below
+    __builtin_amdgcn_sched_barrier(0);
+    double un[M];
+    RollProbe<M> pr;
+    const State Nx = roll_step<M, true, false, PK, false>(P, C, DK, i, b, q, writer, vb, sB, 1.0, Sx, Sn, un,
+                                                          [&](RollIn<M>& R) { roll_load<M, false>(P, i, b, q, vb, sB, R); }, &pr RST_ARG);
+    state_terms(i, pr.e);
+    __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      double sacc = bld(rG, GK_VG(b, M), GOFF(a, 12, M));
+      c1 += bld(rR, REC_VR(b), FOFF(REC_LU + a)) * pr.du[a];
 #pragma unroll
-      for (int k = 0; k < 12; k++) sacc += bld(rG, GK_VG(b, M), GOFF(a, k, M)) * e[k];
-      du[a] = sacc;
+      for (int k = 0; k < M; k++) c2 += pr.du[a] * 2.0 * C.R[a * M + k] * pr.du[k];
+      if (P.al_lb) c2 += pr.du[a] * bld(rR, REC_VR(b), FOFF(P.fLUU + a)) * pr.du[a];
     }
-#pragma unroll
-    for (int a = 0; a < M; a++) {
-      c1 += bld(rR, REC_VR(b), FOFF(REC_LU + a)) * du[a];
-#pragma unroll
-      for (int k = 0; k < M; k++) c2 += du[a] * 2.0 * C.R[a * M + k] * du[k];
-      if (P.al_lb) c2 += du[a] * bld(rR, REC_VR(b), FOFF(P.fLUU + a)) * du[a];
-    }
-    double lin[12], d[12];
-    fx_apply<M>(P, C, i, b, e, du, lin);
-#pragma unroll
-    for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
-    State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
-    Pose D = se3_exp(v3(lin[0] + d[0], lin[1] + d[1], lin[2] + d[2]), v3(lin[3] + d[3], lin[4] + d[4], lin[5] + d[5]));
-    Sn.X = se3_project(se3_compose(Sx.X, D));
-    Sn.w = Sx.w + v3(lin[6] + d[6], lin[7] + d[7], lin[8] + d[8]);
-    Sn.v = Sx.v + v3(lin[9] + d[9], lin[10] + d[10], lin[11] + d[11]);
+    Sn = Nx;
   }
+  {  // terminal knot: deviation of the rolled-out state from the nominal one
+    V3 ew, ev;
+    se3_log(se3_compose(se3_inverse(So.X), Sn.X), ew, ev);
+    const double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                          Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+    state_terms(N, e);
+  }
+  if (!writer) return;
   P.ecc[2 * b] = c1;
   P.ecc[2 * b + 1] = c2;
   double dn = P.dn[b], wprev = P.dweight[2 * b + 1], w;
@@ -3604,18 +3750,35 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
 }
 template <int M, bool MS>
 static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a0, int n, int linear) {
-  {
+  // alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.  A one-alpha stage writes its candidate in
+  // place (no slot, no copy); a trajectory that has accepted leaves the later stages at once.
+  const int direct = n == 1;
+  if (n > NSLOT) return TOLG_E_ARG;
+  if (!direct) {
     Timed t(h, st, 1);
-    dim3 grid((P.Bp + 63) / 64, n), blk(64);
-    if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true>), grid, blk, 0, st, P, a0, n);
-    else hipLaunchKernelGGL((k_rollout_eval<M, MS, false>), grid, blk, 0, st, P, a0, n);
+    dim3 grid((P.Bp + 63) / 64, n), blk(64);  // one thread per (trajectory, alpha)
+    if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n);
+    else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n);
+    LAUNCH_CHECK();
+  } else {
+    Timed t(h, st, 1);
+    dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per trajectory
+    if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
+      if (linear) hipLaunchKernelGGL((k_rollout_eval<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct);
+      else hipLaunchKernelGGL((k_rollout_eval<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct);
+    } else {
+      if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true, 0>), grid, blk, 0, st, P, a0, n, direct);
+      else hipLaunchKernelGGL((k_rollout_eval<M, MS, false, 0>), grid, blk, 0, st, P, a0, n, direct);
+    }
     LAUNCH_CHECK();
   }
   hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n);
   LAUNCH_CHECK();
-  size_t nn = (size_t)(P.N + 1) * P.Bp;
-  hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
-  LAUNCH_CHECK();
+  if (!direct) {
+    size_t nn = (size_t)(P.N + 1) * P.Bp;
+    hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
+    LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
   LAUNCH_CHECK();
   return 0;
@@ -3642,13 +3805,19 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
     } else {
       hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
       LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_expected_change<M>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+      if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
+        hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+      else
+        hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
       LAUNCH_CHECK();
-      // 20 alphas in four stages: the common first-try accept costs one rollout
+      // staged: the first try alone (the common accept: one quad rollout, written in place), then 4 + 8 (+ 7) alphas
+      // of the trajectories still undecided -- iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20
+      // (:2472).  Measured: the merit search of this workload rarely accepts the first alpha, and one stage of 19
+      // took 5.2 ms against 3 x 0.7.
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
-      if (!so3_family(h->prob.kind))  // iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20 (:2472)
+      if (!so3_family(h->prob.kind))
         if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
@@ -3662,7 +3831,7 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
 }
 
 // iLQR_Tracking_SE3 loop body (traopt_controller.py:1926-2007): gradient test and backward pass share
-// one sweep; 13-alpha backtracking in three speculative stages
+// one sweep; 13-alpha backtracking in two speculative stages (the first try, then the other twelve)
 template <int M>
 static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
@@ -3671,8 +3840,7 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
     if ((rc = run_ls_stage<M, false>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
-    if ((rc = run_ls_stage<M, false>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
-    if ((rc = run_ls_stage<M, false>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 1, NALPHA_SS - 1, opt->rollout_linear))) return rc;
     hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
     if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0))) return rc;
