@@ -11,7 +11,10 @@
 //    ~55 copies out of them per knot, and a wait at the top of every step.  Here one LDS-DMA burst (4-5
 //    global_load_lds_dwordx4, 1 KB each, fully coalesced: the four trajectories of a wave own one contiguous run per
 //    knot) brings a knot into a 2-slot LDS ring a whole step ahead, and each lane picks its fields with ds_read
-//    straight into the registers that use them.  Structural zeros are read from a zeroed LDS pad.
+//    straight into the registers that use them.  Structural zeros are read from a zeroed LDS pad.  The velocity block
+//    F_x[6:12,6:12] = I + H dt is not in the record at all (REC_XI, the knot's twist, is): with diagonal inertia blocks
+//    a column of it is the identity column plus, per 3x3 block, two entries of the form alpha w_k + beta v_k with
+//    lane constants -- 18 multiply-adds against 30 fields of record (three LDS-DMA instructions per knot, not four).
 // 2. F_u = [0; B] with B = D S (D diagonal m x m, S a row selector), so Q_uu = 2R + D (V + mu I)_SS D is congruent to
 //    Mt = (V + mu I)_SS + 2 D^-1 R D^-1 (+ D^-1 l_uu^AL D^-1), and Q_ux = D G with G = rows S of (V + mu I) F_x.
 //    Mt's columns already sit in the lanes that hold the columns of V_SS: no T = B^T V product, no row shift; the
@@ -158,13 +161,17 @@ TOLG_DEV void ldl3_backward(const double (&a)[M], const double (&rinv)[M], const
 
 // LDS slot: up to 5 KB of records (REC_FMAX fields x 32 bytes = 4288), then a 256-byte pad of zeros at the same
 // offset in both slots (lane offsets are slot-independent; the slot base is an instruction immediate)
-enum { B3_DATA = 5120, B3_ZBYTES = 256, B3_SLOT = B3_DATA + B3_ZBYTES,
+enum { B3_DATA = 5120, B3_ZBYTES = 256,
+       // the identity columns the lanes of the velocity block start from: six lanes x three 16-byte pairs 64 bytes apart
+       // (the shape of a column read from the record), also at the same offset in both slots
+       B3_ID = B3_DATA + B3_ZBYTES, B3_IDBYTES = 6 * 192, B3_SLOT = B3_ID + B3_IDBYTES,
        // transpose scratch of the symmetrisation: [trajectory][row][14] doubles (even stride: a row is six aligned
        // 16-byte pairs), then a dump for the writes of the lanes that hold no matrix column
        B3_TRS = 14, B3_TR = 2 * B3_SLOT, B3_TRBYTES = 4 * 12 * B3_TRS * 8, B3_DUMP = B3_TR + B3_TRBYTES,
-       B3_LDS = B3_DUMP + 12 * B3_TRS * 8 };
+       // per-lane constants of the velocity-block rebuild: [lane of the row j][16] doubles, read back every knot (in
+       // registers they pushed 14 more values into AGPRs: +0.03 ms)
+       B3_KC = B3_DUMP + 12 * B3_TRS * 8, B3_LDS = B3_KC + 16 * 16 * 8 };
 
-// GRAV: the model has a gravity block A21 in F_x (Drone / RigidBody); SE3 / SO3 instantiate without it.
 // AL: augmented-Lagrangian solve (the records carry the l_uu diagonal; decides the record size with M and GRAV).
 template <int M, bool GRAV, bool AL>
 __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
@@ -184,6 +191,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   if (lane < B3_ZBYTES / 8) {
     reinterpret_cast<double*>(lds + B3_DATA)[lane] = 0.0;
     reinterpret_cast<double*>(lds + B3_SLOT + B3_DATA)[lane] = 0.0;
+  }
+  for (int k = lane; k < B3_IDBYTES / 8; k += 64) {  // identity column c6 = k / 24: row r at pair r / 2 (64 bytes apart), half r % 2
+    const int c6 = k / 24, w = k % 24, pr = w / 8, hf = w % 8;
+    const double v = (hf < 2 && 2 * pr + hf == c6) ? 1.0 : 0.0;
+    reinterpret_cast<double*>(lds + B3_ID)[k] = v;
+    reinterpret_cast<double*>(lds + B3_SLOT + B3_ID)[k] = v;
   }
   __builtin_amdgcn_wave_barrier();
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -220,11 +233,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   else if (j < 9) { fT = REC_JR + 3 * (j - 6); fM = REC_QR + 3 * (j - 6); hT = true; hM = true; }
   else if (j < 12) { fM = REC_JR + 3 * (j - 9); hM = true; }
   else if (j == 12 && !closed) { hT = true; hM = true; }
-  const bool hasB = (j >= 6 && j < 12) || (j == 12 && !closed), isVec = (j == 12 || j == 13);
-  const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
+  const bool vcol = j >= 6 && j < 12;  // columns of the velocity block
+  const bool hasB = (j == 12 && !closed), isVec = (j == 12 || j == 13);
+  const int fB = REC_D + 6;
   const bool hL = (j < 6 || isVec);
   // LDS byte offsets inside a slot (the slot base is added as an immediate); fields that are structurally zero for
-  // this lane point into the zeroed pad.  Loads of pairs use bases on even fields (REC_A22, REC_D, REC_LX, REC_LU).
+  // this lane point into the zeroed pad.  Loads of pairs use bases on even fields (REC_D, REC_LX, REC_LU).
   const unsigned lg = (unsigned)g * 16u;
   const unsigned ZP = (unsigned)B3_DATA;
   unsigned oT[3], oM[3], oL[6];
@@ -232,12 +246,55 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   for (int r = 0; r < 3; r++) { oT[r] = hT ? lg + FOFF(fT + r) : ZP; oM[r] = hM ? lg + FOFF(fM + r) : ZP; }
 #pragma unroll
   for (int r = 0; r < 6; r++) oL[r] = hL ? lg + FOFF((j < 6) ? REC_LXX + sym6(r, j) : REC_LX + r) : ZP;
-  const unsigned oB = hasB ? lg + FOFF(fB) : ZP;                 // rows 6..11 of the column: three 16-byte pairs
+  // rows 6..11 of the column, three 16-byte pairs: the defect (vector column of an open trajectory), the identity
+  // column the velocity block is built on, zeros
+  const unsigned oB = hasB ? lg + FOFF(fB) : vcol ? (unsigned)B3_ID + (unsigned)(j - 6) * 192u : ZP;
+  // velocity block, column c6 = j - 6 = 3 Cb + cc: I + dt J^-1 (coadjoint([v, w]) J + G) (a22_build; swapped twist of
+  // App. C-Q1 included).  With J = blkdiag(diag(a), diag(c)) and S(x)[r][c] = sg(r,c) x_k, k = 3 - r - c, the only
+  // non-zero off-diagonal entries of the column sit in rows kA = cc + 1 and kB = cc + 2 (mod 3) of each block row:
+  //   block (0,0): dt / a_r sg (a_k w_k - a_cc v_k)      block (0,1): dt / a_r sg (m v_k - c_cc w_k)
+  //   block (1,0): dt / c_r sg m v_k                       block (1,1): -dt / c_r sg c_cc v_k
+  // SO3 family (no swap, traopt_dynamics.py:385-400): block (0,0) dt / a_r sg (a_k - a_cc) w_k, nothing else.
+  unsigned oXA = lg + FOFF(REC_XI), oXB = oXA;  // the (w_k, v_k) pairs of k = kA, kB (REC_XI is stored w0 v0 w1 v1 w2 v2)
+  {
+    double aA[2] = {0, 0}, bA[2] = {0, 0}, aB[2] = {0, 0}, bB[2] = {0, 0}, mA[3] = {0, 0, 0}, mB[3] = {0, 0, 0};
+    if (vcol) {
+      const Consts& G = *P.c;
+      const int Cb = (j - 6) / 3, cc = (j - 6) % 3, kA = (cc + 1) % 3, kB = (cc + 2) % 3;
+      auto sg = [](int r, int c) { return ((c - r + 3) % 3 == 1) ? -1.0 : 1.0; };
+      const double dt = G.dt, ms = G.mass;
+      const double iaA = G.Ibinv[4 * kA], iaB = G.Ibinv[4 * kB], icA = G.Jvinv[4 * kA], icB = G.Jvinv[4 * kB];
+      const double a_kA = G.Ib[4 * kA], a_kB = G.Ib[4 * kB], a_cc = G.Ib[4 * cc], c_cc = G.Jv[4 * cc];
+      const double sA = sg(kA, cc), sB_ = sg(kB, cc);
+      if (so3_family(G.kind)) {
+        if (Cb == 0) { aA[0] = dt * iaA * sA * (a_kB - a_cc); aB[0] = dt * iaB * sB_ * (a_kA - a_cc); }
+      } else if (Cb == 0) {
+        aA[0] = dt * iaA * sA * a_kB; bA[0] = -dt * iaA * sA * a_cc;
+        aB[0] = dt * iaB * sB_ * a_kA; bB[0] = -dt * iaB * sB_ * a_cc;
+        bA[1] = dt * icA * sA * ms; bB[1] = dt * icB * sB_ * ms;
+      } else {
+        aA[0] = -dt * iaA * sA * c_cc; bA[0] = dt * iaA * sA * ms;
+        aB[0] = -dt * iaB * sB_ * c_cc; bB[0] = dt * iaB * sB_ * ms;
+        bA[1] = -dt * icA * sA * c_cc; bB[1] = -dt * icB * sB_ * c_cc;
+      }
+      mA[kA] = 1.0; mB[kB] = 1.0;
+      oXA = lg + FOFF(REC_XI + 2 * kA); oXB = lg + FOFF(REC_XI + 2 * kB);
+    }
+    if (g == 0) {  // one row of the table per lane index j: the four trajectories of the wave share it
+      double* kc = reinterpret_cast<double*>(lds + B3_KC) + 16 * j;
+      kc[0] = aA[0]; kc[1] = bA[0]; kc[2] = aB[0]; kc[3] = bB[0]; kc[4] = bA[1]; kc[5] = bB[1];
+#pragma unroll
+      for (int r = 0; r < 3; r++) { kc[6 + 2 * r] = mA[r]; kc[7 + 2 * r] = mB[r]; }
+    }
+  }
+  const unsigned oKC = (unsigned)B3_KC + 128u * (unsigned)j;
   const unsigned oV = isVec ? lg + FOFF(REC_LX + 6) : ZP;        // l_x[6:12] (vector columns)
   const unsigned oU = isVec ? lg + FOFF(REC_LU) : ZP;            // l_u (vector columns)
   const unsigned oG = lg + FOFF(REC_LU + M);                     // gravity direction (every lane), GRAV only
   constexpr bool al = AL;
-  constexpr unsigned blockBytes = (unsigned)rec_fields(M, GRAV, AL) * 32u;  // one knot of this wave's four trajectories
+  constexpr unsigned blockBytes = (unsigned)rec_fields(M, GRAV, AL, false) * 32u;  // one knot of this wave's four trajectories
+  constexpr int NKB = (int)((blockBytes + 1023u) / 1024u);                        // LDS-DMA instructions per knot (3 or 4)
+  static_assert(NKB == 3 || NKB == 4, "record block of four trajectories: 3 or 4 KB");
   const unsigned oUU = (al && mycol >= 0) ? lg + FOFF(P.fLUU + (mycol >= 0 ? mycol : 0)) : ZP;  // l_uu^AL[c][c] in the lane of Mt's column c
   // symmetrisation scratch: lane j < 12 writes its column (entry r at row r) and reads row j back as six pairs;
   // the vector lanes write into the dump, read zeros and scale by 1 instead of 1/2
@@ -262,8 +319,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   auto dma_knot = [&](int i, int s) {
     const char* src = reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes;
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)s * B3_SLOT));
-    rl_dma16x4(uniform_ptr(src), (unsigned)lane * 16u, dst);
-    if constexpr (blockBytes > 4096u) rl_dma16(src + 4096 + (size_t)lane * 16, dst + 4096);
+    if constexpr (NKB == 3) rl_dma16x3(uniform_ptr(src), (unsigned)lane * 16u, dst);
+    else rl_dma16x4(uniform_ptr(src), (unsigned)lane * 16u, dst);
   };
 
   // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
@@ -308,7 +365,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // the last step's gain stores and record request" is a counted wait.  (Step 0 is preceded by a step that
     // requested nothing.)
     if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + (blockBytes > 4096u ? 5 : 4)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + NKB) : "memory");
     double A[12], Qh[12], lu[M], luu_i = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; r++) { A[r] = ld(oT[r]); A[3 + r] = ld(oM[r]); }
@@ -328,12 +385,24 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #pragma unroll
       for (int r = 0; r < 6; r++) A[6 + r] += gv[0] * Cg[0][r] + gv[1] * Cg[1][r] + gv[2] * Cg[2][r];
     }
+    // twist pairs and lane constants of the velocity-block rebuild (used between the two halves of the Z product)
+    const f64x2 xA = *reinterpret_cast<const f64x2*>(sl + oXA), xB = *reinterpret_cast<const f64x2*>(sl + oXB);  // (w, v) of kA, kB
+    const f64x2* kc = reinterpret_cast<const f64x2*>(lds + oKC);
+    const f64x2 c0 = kc[0], c1 = kc[1], c2 = kc[2];  // aA0 bA0 | aB0 bB0 | bA1 bB1
+    const f64x2 mk0 = kc[3], mk1 = kc[4], mk2 = kc[5];  // (row r == kA, row r == kB), r = 0..2
     STAMP(0)
     // ---- Z = V [F_x | d]  (+ V_x in the vector column -> w = V_x + V_xx d; the adjoint passes through)
     double Z[12];
 #pragma unroll
     for (int r = 0; r < 12; r++) Z[r] = (1.0 - m12) * V[r];
     rank1_bk3_0(Z, V, A[0], A[1], A[2]); rank1_bk3_3(Z, V, A[3], A[4], A[5]);
+    {  // velocity block of F_x on top of its identity column (lanes 6..11; every constant is zero elsewhere); here, behind
+      // the first half of the product, its LDS reads have long returned
+      const double eA0 = fma(c0.x, xB.x, c0.y * xB.y), eB0 = fma(c1.x, xA.x, c1.y * xA.y), eA1 = c2.x * xB.y, eB1 = c2.y * xA.y;
+      A[6] = fma(mk0.y, eB0, fma(mk0.x, eA0, A[6])); A[9] = fma(mk0.y, eB1, fma(mk0.x, eA1, A[9]));
+      A[7] = fma(mk1.y, eB0, fma(mk1.x, eA0, A[7])); A[10] = fma(mk1.y, eB1, fma(mk1.x, eA1, A[10]));
+      A[8] = fma(mk2.y, eB0, fma(mk2.x, eA0, A[8])); A[11] = fma(mk2.y, eB1, fma(mk2.x, eA1, A[11]));
+    }
     rank1_bk3_6(Z, V, A[6], A[7], A[8]); rank1_bk3_9(Z, V, A[9], A[10], A[11]);
     STAMP(1)
     // the slot is consumed (every ds_read above has returned: Z needed them): last knot's gains go out, then the

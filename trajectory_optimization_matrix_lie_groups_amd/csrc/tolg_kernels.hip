@@ -72,6 +72,7 @@ struct Params {
   const double* ref;   // [N+1][13] reference pose (quat, pos) and twist, batch-shared
   double* REC;         // [N+1][recF][Bp] compact knot records written by K1 (fields: REC_*)
   int recF, fLUU;      // fields per record for this model / solve (rec_fields()), field index of REC_LUU (AL only)
+  int fA22, pad2;      // field index of the stored I + H dt block, -1 when the backward sweep rebuilds it from REC_XI
   double* SC;          // [N+1][Bp] stage costs
   double* SD;          // [N][Bp]   squared defects
   double* GK;          // [N][m*13][Bp]     K (cols 0..11) | k (col 12), row-major per knot
@@ -142,19 +143,27 @@ enum {
   REC_D = 36,    // defect (12)
   REC_LXX = 48,  // l_xx pose block, symmetric packed (21; 69 is padding: pairs below)
   REC_LX = 70,   // l_x (12)
-  REC_A22 = 82,  // I + H dt (6x6, column-major)         -> F_x[6:12,6:12]
-  REC_LU = 118,  // l_u = 2 R u (+ augmented-Lagrangian term) (m)
-  REC_BASE = 118,
+  REC_XI = 82,   // the twist of the knot (6, stored w0 v0 w1 v1 w2 v2): what F_x[6:12,6:12] = I + H dt is a function of
+  REC_LU = 88,   // l_u = 2 R u (+ augmented-Lagrangian term) (m)
+  REC_BASE = 88,
   // REC_LU + m: R^T (0,0,-1) (gravity direction in the body frame, 3 + 1 padding), gravity models only
   // Params::fLUU: diagonal added to l_uu = 2 R by the augmented Lagrangian (m), AL solves only
-  REC_FMAX = REC_BASE + 6 + 4 + 6,
+  // Params::fA22: I + H dt itself (6x6, column-major, 36 fields), only for the models whose backward sweep reads it
+  // from the record (dense inertia, pendulum: k_backward).  With diagonal inertia blocks -- every reference script --
+  // a column of I + H dt is two entries of the form alpha w_k + beta v_k per 3x3 block, which k_backward3 rebuilds
+  // from the twist: 30 of the 112 fields a fused launch wrote per knot in round 2 (the launch is paced by its memory
+  // traffic: -0.04 ms measured then), and a knot of records of four trajectories fits three 1 KB LDS-DMA
+  // instructions of the backward sweep instead of four.
+  REC_FMAX = REC_BASE + 6 + 4 + 6 + 36,
   // Pendulum3dDyanmics only: F_u[6:9,0:3] = J^-1 skew(m rho) R^T dt (state dependent), row-major, in the
   // slot of REC_TRI -- that block of F_x is identically zero without a translation, and an extra
   // field would leave a never-written hole in every record group of all the other models
   REC_BU = REC_TRI
 };
 __host__ __device__ inline int rec_rte(int m) { return REC_LU + m; }
-__host__ __device__ constexpr int rec_fields(int m, bool grav, bool al) { return REC_BASE + m + (grav ? 4 : 0) + (al ? m : 0); }
+__host__ __device__ constexpr int rec_fields(int m, bool grav, bool al, bool a22) {
+  return REC_BASE + m + (grav ? 4 : 0) + (al ? m : 0) + (a22 ? 36 : 0);
+}
 // Records and gains are interleaved by four trajectories and by field pairs:
 // REC [knot][b / 4][field / 2][b % 4][field % 2], GK [knot][b / 4][column j][row u / 2][b % 4][u % 2].
 // The four trajectories of one K2 wavefront then own one contiguous run per knot (every 64-byte
@@ -439,6 +448,57 @@ __global__ void k_init_rollout(Params P) {
   }
 }
 
+// A22 = I + H dt (column-major), H = J^-1 (coadjoint([v, w]) J + G)  <- literal swapped twist (App. C-Q1)
+// (traopt_dynamics.py:802-837, :1416-1469).  With J = blkdiag(Ib, Jv):
+// coadjoint([v,w]) J + G = [[S(Ib w) - Sv Ib, m Sv - Sw Jv],[m Sv, -Sv Jv]]
+template <class CT>
+TOLG_DEV void a22_build(const CT& C, V3 w, V3 v, double (&a22)[36]) {
+  const double dt = C.dt;
+  double Sv[9], Sw[9], SIw[9], M11[9], M12[9], M21[9], M22[9], T1[9], T2[9];
+  skew(v, Sv);
+  skew(w, Sw);
+  skew(mv33(C.Ib, w), SIw);
+  mul33(Sv, C.Ib, T1);
+  mul33(Sw, C.Jv, T2);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = C.mass * Sv[k] - T2[k]; M21[k] = C.mass * Sv[k]; }
+  mul33(Sv, C.Jv, T1);
+#pragma unroll
+  for (int k = 0; k < 9; k++) M22[k] = -T1[k];
+  if (so3_family(C.kind)) {
+    // SO3Dynamics.f_x (and Pendulum3dDyanmics.f_x :566-567) (traopt_dynamics.py:385-400): H = J^-1 (skew(w)^T J + skew(J w)) -- the SO(3)
+    // model has no swapped-twist quirk; the unused linear-velocity block is the identity
+    mul33(Sw, C.Ib, T1);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = 0; M21[k] = 0; M22[k] = 0; }
+  }
+  double H11[9], H12[9], H21[9], H22[9];
+  mul33(C.Ibinv, M11, H11);
+  mul33(C.Ibinv, M12, H12);
+  mul33(C.Jvinv, M21, H21);
+  mul33(C.Jvinv, M22, H22);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double id = (r == c) ? 1.0 : 0.0;
+      a22[6 * c + r] = id + dt * H11[3 * r + c];
+      a22[6 * (c + 3) + r] = dt * H12[3 * r + c];
+      a22[6 * c + r + 3] = dt * H21[3 * r + c];
+      a22[6 * (c + 3) + r + 3] = id + dt * H22[3 * r + c];
+    }
+}
+// the block of knot i of trajectory b, from the record where it is stored, from the record's twist where it is not
+TOLG_DEV void a22_get(const Params& P, const Consts& C, int i, int b, double (&a22)[36]) {
+  if (P.fA22 >= 0) {
+#pragma unroll
+    for (int k = 0; k < 36; k++) a22[k] = P.REC[RIDX(i, P.fA22 + k, b)];
+  } else {
+    a22_build(C, v3(P.REC[RIDX(i, REC_XI, b)], P.REC[RIDX(i, REC_XI + 2, b)], P.REC[RIDX(i, REC_XI + 4, b)]),
+              v3(P.REC[RIDX(i, REC_XI + 1, b)], P.REC[RIDX(i, REC_XI + 3, b)], P.REC[RIDX(i, REC_XI + 5, b)]), a22);
+  }
+}
+
 // N consecutive record fields from F0, as 16-byte stores wherever a field pair is complete
 template <int F0, int N>
 TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
@@ -644,43 +704,17 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
     }
   }
   {
-    // A22 = I + H dt, H = J^-1 (coadjoint([v, w]) J + G)  <- literal swapped twist (App. C-Q1)
-    // with J = blkdiag(Ib, Jv): coadjoint([v,w]) J + G = [[S(Ib w) - Sv Ib, m Sv - Sw Jv],[m Sv, -Sv Jv]]
-    double Sv[9], Sw[9], SIw[9], M11[9], M12[9], M21[9], M22[9], T1[9], T2[9];
-    skew(S.v, Sv);
-    skew(S.w, Sw);
-    skew(mv33(C.Ib, S.w), SIw);
-    mul33(Sv, C.Ib, T1);
-    mul33(Sw, C.Jv, T2);
+    const double xi6[6] = {S.w.x, S.v.x, S.w.y, S.v.y, S.w.z, S.v.z};  // (w_k, v_k) pairs: one 16-byte read each in k_backward3
+    rec_run<REC_XI, 6>(P, i, b, xi6);
+    if (P.fA22 >= 0) {  // kernel-uniform: the models whose backward sweep reads the block from the record
+      double a22[36];
+      a22_build(C, S.w, S.v, a22);
 #pragma unroll
-    for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = C.mass * Sv[k] - T2[k]; M21[k] = C.mass * Sv[k]; }
-    mul33(Sv, C.Jv, T1);
-#pragma unroll
-    for (int k = 0; k < 9; k++) M22[k] = -T1[k];
-    if (so3_family(C.kind)) {
-      // SO3Dynamics.f_x (and Pendulum3dDyanmics.f_x :566-567) (traopt_dynamics.py:385-400): H = J^-1 (skew(w)^T J + skew(J w)) -- the SO(3)
-      // model has no swapped-twist quirk; the unused linear-velocity block is the identity
-      mul33(Sw, C.Ib, T1);
-#pragma unroll
-      for (int k = 0; k < 9; k++) { M11[k] = SIw[k] - T1[k]; M12[k] = 0; M21[k] = 0; M22[k] = 0; }
-    }
-    double H11[9], H12[9], H21[9], H22[9];
-    mul33(C.Ibinv, M11, H11);
-    mul33(C.Ibinv, M12, H12);
-    mul33(C.Jvinv, M21, H21);
-    mul33(C.Jvinv, M22, H22);
-    double a22[36];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        double id = (r == c) ? 1.0 : 0.0;
-        a22[6 * c + r] = id + dt * H11[3 * r + c];
-        a22[6 * (c + 3) + r] = dt * H12[3 * r + c];
-        a22[6 * c + r + 3] = dt * H21[3 * r + c];
-        a22[6 * (c + 3) + r + 3] = id + dt * H22[3 * r + c];
+      for (int k = 0; k < 36; k += 2) {
+        f64x2 w2 = {a22[k], a22[k + 1]};
+        *reinterpret_cast<f64x2*>(&P.REC[RIDX(i, P.fA22 + k, b)]) = w2;
       }
-    rec_run<REC_A22, 36>(P, i, b, a22);
+    }
   }
   if (C.grav != 0.0) {  // gravity models only (the field does not exist otherwise)
     V3 rte = qrot_inv(S.X.q, v3(0, 0, -1.0));
@@ -1688,7 +1722,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
   const double mLT = (j < 6 || j == 12 || j == 13) ? 1.0 : 0.0;
   // rows 6..11 of column j: lanes 6..11 read their A22 column, lane 12 reads d[6:12], lanes 0..2
   // (gravity models) build their A21 column from R^T e3 with per-lane constants
-  const int fB = (j >= 6 && j < 12) ? REC_A22 + 6 * (j - 6) : REC_D + 6;
+  const int fB = (j >= 6 && j < 12) ? P.fA22 + 6 * (j - 6) : REC_D + 6;  // (this sweep's models store the block)
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   const unsigned vr = REC_VR(b);
   // Lanes for which a block of the column is structurally zero load it from an out-of-range offset: raw
@@ -2055,11 +2089,13 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
   }
   double rte[3] = {0, 0, 0};  // the field exists for gravity models only
   if (C.grav != 0.0) { rte[0] = P.REC[RIDX(i, REC_LU + M, b)]; rte[1] = P.REC[RIDX(i, REC_LU + M + 1, b)]; rte[2] = P.REC[RIDX(i, REC_LU + M + 2, b)]; }
+  double a22[36];
+  a22_get(P, C, i, b, a22);
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     double sacc = e[6 + r];
 #pragma unroll
-    for (int c = 0; c < 6; c++) sacc += (P.REC[RIDX(i, REC_A22 + 6 * c + r, b)] - (r == c ? 1.0 : 0.0)) * e[6 + c];
+    for (int c = 0; c < 6; c++) sacc += (a22[6 * c + r] - (r == c ? 1.0 : 0.0)) * e[6 + c];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       double l = rte[0] * C.Llin[0][6 * r + c] + rte[1] * C.Llin[1][6 * r + c] + rte[2] * C.Llin[2][6 * r + c];
@@ -2419,6 +2455,14 @@ TOLG_DEV void rl_dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+TOLG_DEV void rl_dma16x3(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
@@ -3283,11 +3327,13 @@ __global__ void k_probe_export(Params P, int i, double* __restrict__ f_q, double
       }
     double rte[3];
     for (int a = 0; a < 3; a++) rte[a] = (C.grav != 0.0) ? P.REC[RIDX(i, rec_rte(P.m) + a, b)] : 0.0;
+    double a22[36];
+    a22_get(P, C, i, b, a22);
     for (int r = 0; r < 6; r++)
       for (int c = 0; c < 6; c++) {
         double lsum = 0;
         for (int a = 0; a < 3; a++) lsum += rte[a] * C.Llin[a][6 * r + c];
-        F[12 * (r + 6) + c + 6] = P.REC[RIDX(i, REC_A22 + 6 * c + r, b)];
+        F[12 * (r + 6) + c + 6] = a22[6 * c + r];
         F[12 * (r + 6) + c] = lsum;
       }
   }
@@ -3319,11 +3365,13 @@ __global__ void k_export_lin(Params P, double* __restrict__ Fx, double* __restri
       }
     double rte[3];
     for (int a = 0; a < 3; a++) rte[a] = (C.grav != 0.0) ? P.REC[RIDX(i, rec_rte(P.m) + a, b)] : 0.0;
+    double a22[36];
+    a22_get(P, C, i, b, a22);
     for (int r = 0; r < 6; r++)
       for (int c = 0; c < 6; c++) {
         double l = 0;
         for (int a = 0; a < 3; a++) l += rte[a] * C.Llin[a][6 * r + c];
-        F[12 * (r + 6) + c + 6] = P.REC[RIDX(i, REC_A22 + 6 * c + r, b)];
+        F[12 * (r + 6) + c + 6] = a22[6 * c + r];
         F[12 * (r + 6) + c] = l;
       }
   }
@@ -3677,8 +3725,12 @@ static Params params_for(tolg_handle_s* h, int B) {
   P.max_iter = 0; P.tol_grad = 0; P.tol_defect = 0; P.max_reg = 1e10;
   P.al_lb = h->al_lb; P.al_ub = h->al_ub; P.al_lambda = h->al_lambda; P.al_imu = h->al_imu;
   const bool grav = h->hc.grav != 0.0;
-  P.recF = rec_fields(P.m, grav, P.al_lb != nullptr);
+  // the velocity block of F_x is stored only for the models the third form of the backward sweep does not cover
+  const bool a22 = !(h->hc.diagJ != 0 && h->prob.kind != TOLG_DYN_PENDULUM3D);
+  P.recF = rec_fields(P.m, grav, P.al_lb != nullptr, a22);
   P.fLUU = REC_LU + P.m + (grav ? 4 : 0);
+  P.fA22 = a22 ? P.fLUU + (P.al_lb != nullptr ? P.m : 0) : -1;
+  P.pad2 = 0;
   return P;
 }
 
