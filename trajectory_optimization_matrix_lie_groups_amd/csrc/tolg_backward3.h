@@ -38,40 +38,40 @@ template <int M, int J, int LN>
 TOLG_DEV void ldl3_update(double (&a)[M], double w) {
   constexpr int R = M - 1 - J;
   if constexpr (R == 5)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%5", "%6") DF3("%1", "%1", "%5", "%6") DF3("%2", "%2", "%5", "%6")
+    asm volatile(DF3("%0", "%0", "%5", "%6") DF3("%1", "%1", "%5", "%6") DF3("%2", "%2", "%5", "%6")
                      DF3("%3", "%3", "%5", "%6") DF3("%4", "%4", "%5", "%6")
                  : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]), "+v"(a[J + 5]) : "v"(w), "n"(LN));
   if constexpr (R == 4)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%4", "%5") DF3("%1", "%1", "%4", "%5") DF3("%2", "%2", "%4", "%5")
+    asm volatile(DF3("%0", "%0", "%4", "%5") DF3("%1", "%1", "%4", "%5") DF3("%2", "%2", "%4", "%5")
                      DF3("%3", "%3", "%4", "%5")
                  : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]), "+v"(a[J + 4]) : "v"(w), "n"(LN));
   if constexpr (R == 3)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%3", "%4") DF3("%1", "%1", "%3", "%4") DF3("%2", "%2", "%3", "%4")
+    asm volatile(DF3("%0", "%0", "%3", "%4") DF3("%1", "%1", "%3", "%4") DF3("%2", "%2", "%3", "%4")
                  : "+v"(a[J + 1]), "+v"(a[J + 2]), "+v"(a[J + 3]) : "v"(w), "n"(LN));
   if constexpr (R == 2)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%2", "%3") DF3("%1", "%1", "%2", "%3")
+    asm volatile(DF3("%0", "%0", "%2", "%3") DF3("%1", "%1", "%2", "%3")
                  : "+v"(a[J + 1]), "+v"(a[J + 2]) : "v"(w), "n"(LN));
   if constexpr (R == 1)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%0", "%1", "%2") : "+v"(a[J + 1]) : "v"(w), "n"(LN));
+    asm volatile(DF3("%0", "%0", "%1", "%2") : "+v"(a[J + 1]) : "v"(w), "n"(LN));
 }
 // y += sum_{k < I} p@lane urow(k) * q[k]  (row I of the forward substitution; p = this lane's a[I])
 template <int M, int I>
 TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
   if constexpr (I == 1)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
+    asm volatile(DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
   if constexpr (I == 2)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
+    asm volatile(DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0)), "n"(urow<M>(1)));
   if constexpr (I == 3)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%5") DF3("%0", "%1", "%3", "%6") DF3("%0", "%1", "%4", "%7")
+    asm volatile(DF3("%0", "%1", "%2", "%5") DF3("%0", "%1", "%3", "%6") DF3("%0", "%1", "%4", "%7")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "n"(urow<M>(0)), "n"(urow<M>(1)), "n"(urow<M>(2)));
   if constexpr (I == 4)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%6") DF3("%0", "%1", "%3", "%7") DF3("%0", "%1", "%4", "%8")
+    asm volatile(DF3("%0", "%1", "%2", "%6") DF3("%0", "%1", "%3", "%7") DF3("%0", "%1", "%4", "%8")
                      DF3("%0", "%1", "%5", "%9")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "n"(urow<M>(0)), "n"(urow<M>(1)),
                    "n"(urow<M>(2)), "n"(urow<M>(3)));
   if constexpr (I == 5)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%7") DF3("%0", "%1", "%3", "%8") DF3("%0", "%1", "%4", "%9")
+    asm volatile(DF3("%0", "%1", "%2", "%7") DF3("%0", "%1", "%3", "%8") DF3("%0", "%1", "%4", "%9")
                      DF3("%0", "%1", "%5", "%10") DF3("%0", "%1", "%6", "%11")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "n"(urow<M>(0)),
                    "n"(urow<M>(1)), "n"(urow<M>(2)), "n"(urow<M>(3)), "n"(urow<M>(4)));
@@ -80,20 +80,20 @@ TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
 template <int M, int I, int LN>
 TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
   constexpr int R = M - 1 - I;
-  if constexpr (R == 1) asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(t) : "v"(a[I + 1]), "v"(x[I + 1]), "n"(LN));
+  if constexpr (R == 1) asm volatile(DF3("%0", "%1", "%2", "%3") : "+v"(t) : "v"(a[I + 1]), "v"(x[I + 1]), "n"(LN));
   if constexpr (R == 2)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%3", "%5") DF3("%0", "%2", "%4", "%5")
+    asm volatile(DF3("%0", "%1", "%3", "%5") DF3("%0", "%2", "%4", "%5")
                  : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(x[I + 1]), "v"(x[I + 2]), "n"(LN));
   if constexpr (R == 3)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%4", "%7") DF3("%0", "%2", "%5", "%7") DF3("%0", "%3", "%6", "%7")
+    asm volatile(DF3("%0", "%1", "%4", "%7") DF3("%0", "%2", "%5", "%7") DF3("%0", "%3", "%6", "%7")
                  : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(x[I + 1]), "v"(x[I + 2]), "v"(x[I + 3]), "n"(LN));
   if constexpr (R == 4)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%5", "%9") DF3("%0", "%2", "%6", "%9") DF3("%0", "%3", "%7", "%9")
+    asm volatile(DF3("%0", "%1", "%5", "%9") DF3("%0", "%2", "%6", "%9") DF3("%0", "%3", "%7", "%9")
                      DF3("%0", "%4", "%8", "%9")
                  : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(x[I + 1]), "v"(x[I + 2]),
                    "v"(x[I + 3]), "v"(x[I + 4]), "n"(LN));
   if constexpr (R == 5)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%6", "%11") DF3("%0", "%2", "%7", "%11") DF3("%0", "%3", "%8", "%11")
+    asm volatile(DF3("%0", "%1", "%6", "%11") DF3("%0", "%2", "%7", "%11") DF3("%0", "%3", "%8", "%11")
                      DF3("%0", "%4", "%9", "%11") DF3("%0", "%5", "%10", "%11")
                  : "+v"(t) : "v"(a[I + 1]), "v"(a[I + 2]), "v"(a[I + 3]), "v"(a[I + 4]), "v"(a[I + 5]), "v"(x[I + 1]),
                    "v"(x[I + 2]), "v"(x[I + 3]), "v"(x[I + 4]), "v"(x[I + 5]), "n"(LN));
@@ -119,26 +119,64 @@ TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]
 }
 #endif
 
+// Issue costs that shape this code (profiles/r03_valu_issue_microbench.txt, one wave per SIMD, cycles per instruction):
+// v_fma_f64 / v_fmac_f64_dpp 5.6 independent, 8.9 dependent; v_mov_b64 8.2; s_nop 1 8.9; v_rcp_f64 17.  The sweep is
+// the SUM of its issue costs (interleaving independent work into the chains bought nothing), so what counts is the
+// number of instructions and their kind: no hazard nops where the DPP operand is old, no register copies, no
+// zero-initialised accumulators, the negated reciprocal straight from v_rcp_f64(-d).
+//
 // Mt (m x m, column c in lane urow(c)) factored where it lies: right-looking L Dl L^T.  wm[J] is this lane's update
-// mask for pivot J: -1 for the columns right of the pivot, 0 for every other lane (their rows below J are final factor
-// entries, or not part of Mt at all).  On return a[i] (i > c) of lane urow(c) holds L[i][c] Dl_c, rinv[J] = 1 / Dl_J in
-// every lane.  Returns "every pivot > 0".
-template <int M, int J = 0>
-TOLG_DEV bool ldl3_factor(double (&a)[M], double (&rinv)[M], const double (&wm)[M], bool ok = true) {
-  const double d = bcast<urow<M>(J)>(a[J]);
-  ok = ok && (d > 0.0);
-  // a non-positive pivot leaves garbage behind it: the caller discards the factors when !ok.  (One Newton step
-  // instead of two -- 2.2e-15 relative, tools/rcp_accuracy_check.hip -- was measured and is no faster: 0.364 vs 0.360 ms.)
-  rinv[J] = rcp_nr(d);
-  if constexpr (J + 1 < M) {
-    const double w = (a[J] * wm[J]) * rinv[J];
-    ldl3_update<M, J, urow<M>(J)>(a, w);
-    return ldl3_factor<M, J + 1>(a, rinv, wm, ok);
+// mask for pivot J: 1 for the columns right of the pivot, 0 for every other lane (their rows below J are final factor
+// entries, or not part of Mt at all).  On return a[i] (i > c) of lane urow(c) holds L[i][c] Dl_c, nri[J] = -1 / Dl_J in
+// every lane, d[J] the pivots ("every pivot > 0" is the positive-definiteness test).
+#ifndef TOLG_DPP_BUILTIN
+// pivot J broadcast to the row (+ this lane's masked multiplier numerator).  Wait states in front of the DPP read of
+// a[J]: it was written by the first multiply-add of the previous pivot's update, M - 1 - J more of them follow, then
+// the v_mul here -- enough except behind the last update (nothing in between) and at pivot 0 (a[0] comes straight from
+// the instruction in front of the statement).
+template <int M, int J>
+TOLG_DEV void ldl3_head(const double (&a)[M], double wmJ, double& d, double& pre) {
+  if constexpr (J == M - 1) {
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(a[J]), "n"(urow<M>(J)));
+    pre = 0.0;
+  } else if constexpr (J == 0) {
+    asm volatile("v_mul_f64 %1, %2, %3\n\ts_nop 0\n\tv_mov_b64_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J)));
   } else {
-    return ok;
+    asm volatile("v_mul_f64 %1, %2, %3\n\tv_mov_b64_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J)));
   }
 }
-// forward substitution in place: y <- L^-1 y, zn_k = -y_k / Dl_k (nri = -rinv, zeroed in the adjoint lane)
+#else
+template <int M, int J>
+TOLG_DEV void ldl3_head(const double (&a)[M], double wmJ, double& d, double& pre) {
+  d = bcast<urow<M>(J)>(a[J]);
+  pre = a[J] * wmJ;
+}
+#endif
+template <int M, int J = 0>
+TOLG_DEV void ldl3_factor(double (&a)[M], double (&nri)[M], double (&d)[M], const double (&wm)[M]) {
+  double pre;
+  ldl3_head<M, J>(a, wm[J], d[J], pre);
+  // -1 / d: v_rcp_f64 of -d, two Newton steps on x -> x + x (1 + d x).  A non-positive pivot leaves garbage behind it:
+  // the caller discards the factors then.  (One step instead of two, 2.2e-15, was measured and is no faster.)
+  double x = __builtin_amdgcn_rcp(-d[J]);
+  x = fma(x, fma(d[J], x, 1.0), x);
+  x = fma(x, fma(d[J], x, 1.0), x);
+  nri[J] = x;
+  if constexpr (J + 1 < M) {
+    ldl3_update<M, J, urow<M>(J)>(a, pre * x);  // a[i] -= a[i]@pivot lane * a[J] / d for the columns right of the pivot
+    ldl3_factor<M, J + 1>(a, nri, d, wm);
+  }
+}
+template <int M>
+TOLG_DEV bool ldl3_all_positive(const double (&d)[M]) {
+  bool ok = d[0] > 0.0;
+#pragma unroll
+  for (int u = 1; u < M; u++) ok = ok && (d[u] > 0.0);
+  return ok;
+}
+// forward substitution in place: y <- L^-1 y, zn_k = -y_k / Dl_k (nri = -1 / Dl, zeroed in the adjoint lane)
 template <int M>
 TOLG_DEV void ldl3_forward(const double (&a)[M], const double (&nri)[M], double (&y)[M], double (&zn)[M]) {
   zn[0] = y[0] * nri[0];
@@ -148,15 +186,17 @@ TOLG_DEV void ldl3_forward(const double (&a)[M], const double (&nri)[M], double 
   if constexpr (M > 4) { ldl3_fwd_row<M, 4>(y[4], a[4], zn); zn[4] = y[4] * nri[4]; }
   if constexpr (M > 5) { ldl3_fwd_row<M, 5>(y[5], a[5], zn); zn[5] = y[5] * nri[5]; }
 }
-// back substitution: x = -L^-T zn  (= Mt^-1 of the right-hand side), x_i = -(zn_i + (1 / Dl_i) sum_{k>i} a[k]@i x_k)
+// back substitution on nx = -x (x = Mt^-1 of the right-hand side), IN PLACE on the forward result y, which nobody
+// needs any more once the rank-m update has read it: y_i += sum_{k>i} (L Dl)[k][i] nx_k, nx_i = -y_i / Dl_i;
+// nx_{M-1} = zn_{M-1}.  No zero-initialised accumulators, no copies.
 template <int M>
-TOLG_DEV void ldl3_backward(const double (&a)[M], const double (&rinv)[M], const double (&zn)[M], double (&x)[M]) {
-  x[M - 1] = -zn[M - 1];
-  if constexpr (M > 1) { double t = 0; ldl3_bwd_row<M, M - 2, urow<M>(M - 2)>(t, a, x); x[M - 2] = -fma(rinv[M - 2], t, zn[M - 2]); }
-  if constexpr (M > 2) { double t = 0; ldl3_bwd_row<M, M - 3, urow<M>(M - 3)>(t, a, x); x[M - 3] = -fma(rinv[M - 3], t, zn[M - 3]); }
-  if constexpr (M > 3) { double t = 0; ldl3_bwd_row<M, M - 4, urow<M>(M - 4)>(t, a, x); x[M - 4] = -fma(rinv[M - 4], t, zn[M - 4]); }
-  if constexpr (M > 4) { double t = 0; ldl3_bwd_row<M, M - 5, urow<M>(M - 5)>(t, a, x); x[M - 5] = -fma(rinv[M - 5], t, zn[M - 5]); }
-  if constexpr (M > 5) { double t = 0; ldl3_bwd_row<M, M - 6, urow<M>(M - 6)>(t, a, x); x[M - 6] = -fma(rinv[M - 6], t, zn[M - 6]); }
+TOLG_DEV void ldl3_backward_nx(const double (&a)[M], const double (&nri)[M], double (&y)[M], const double (&zn)[M], double (&nx)[M]) {
+  nx[M - 1] = zn[M - 1];
+  if constexpr (M > 1) { ldl3_bwd_row<M, M - 2, urow<M>(M - 2)>(y[M - 2], a, nx); nx[M - 2] = y[M - 2] * nri[M - 2]; }
+  if constexpr (M > 2) { ldl3_bwd_row<M, M - 3, urow<M>(M - 3)>(y[M - 3], a, nx); nx[M - 3] = y[M - 3] * nri[M - 3]; }
+  if constexpr (M > 3) { ldl3_bwd_row<M, M - 4, urow<M>(M - 4)>(y[M - 4], a, nx); nx[M - 4] = y[M - 4] * nri[M - 4]; }
+  if constexpr (M > 4) { ldl3_bwd_row<M, M - 5, urow<M>(M - 5)>(y[M - 5], a, nx); nx[M - 5] = y[M - 5] * nri[M - 5]; }
+  if constexpr (M > 5) { ldl3_bwd_row<M, M - 6, urow<M>(M - 6)>(y[M - 6], a, nx); nx[M - 6] = y[M - 6] * nri[M - 6]; }
 }
 
 // LDS slot: up to 5 KB of records (REC_FMAX fields x 32 bytes = 4288), then a 256-byte pad of zeros at the same
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #pragma unroll
     for (int u = 0; u < M; u++) {
       Rt[u] = (mycol >= 0) ? 2.0 * C.R[u * M + (mycol >= 0 ? mycol : 0)] * ibu[u] * ibc : 0.0;
-      wm[u] = (mycol > u) ? -1.0 : 0.0;
+      wm[u] = (mycol > u) ? 1.0 : 0.0;
     }
   }
   // which record fields make up column j of [F_x | d] (rows 0..2, 3..5) and of [l_xx | l_x]
@@ -395,7 +435,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     double Z[12];
 #pragma unroll
     for (int r = 0; r < 12; r++) Z[r] = (1.0 - m12) * V[r];
-    rank1_bk3_0(Z, V, A[0], A[1], A[2]); rank1_bk3_3(Z, V, A[3], A[4], A[5]);
+    rank1_bk3_0_nn(Z, V, A[0], A[1], A[2]); rank1_bk3_3_nn(Z, V, A[3], A[4], A[5]);
     {  // velocity block of F_x on top of its identity column (lanes 6..11; every constant is zero elsewhere); here, behind
       // the first half of the product, its LDS reads have long returned
       const double eA0 = fma(c0.x, xB.x, c0.y * xB.y), eB0 = fma(c1.x, xA.x, c1.y * xA.y), eA1 = c2.x * xB.y, eB1 = c2.y * xA.y;
@@ -403,7 +443,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       A[7] = fma(mk1.y, eB0, fma(mk1.x, eA0, A[7])); A[10] = fma(mk1.y, eB1, fma(mk1.x, eA1, A[10]));
       A[8] = fma(mk2.y, eB0, fma(mk2.x, eA0, A[8])); A[11] = fma(mk2.y, eB1, fma(mk2.x, eA1, A[11]));
     }
-    rank1_bk3_6(Z, V, A[6], A[7], A[8]); rank1_bk3_9(Z, V, A[9], A[10], A[11]);
+    rank1_bk3_6_nn(Z, V, A[6], A[7], A[8]); rank1_bk3_9_nn(Z, V, A[9], A[10], A[11]);
     STAMP(1)
     // the slot is consumed (every ds_read above has returned: Z needed them): last knot's gains go out, then the
     // records of knot i - 2 come into this slot.  Stores first: the wait at the top of a step covers both, in order.
@@ -415,7 +455,6 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     STAMP(2)
     // ---- regularised G = rows S of (V + mu I)[F_x | d] (+ D^-1 l_u in the vector columns), Mt; PD test
     // (traopt_controller.py:2964-2995, :3052-3060)
-    double Y[M], Uf[M], rinv[M];
     bool use_lu = false;
     double mu_used = 0.0;
     auto build = [&](double mu_, double (&Gm)[M], double (&Mt)[M]) {
@@ -437,11 +476,6 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
         for (int u = 0; u < M; u++) Mt[u] += (mycol == u) ? luu_i * ibu[u] * ibu[u] : 0.0;
       }
     };
-    auto attempt = [&]() -> bool {
-      mu_used = mu;
-      build(mu, Y, Uf);
-      return ldl3_factor<M>(Uf, rinv, wm);
-    };
     // regularisation schedule (traopt_controller.py:2975-2995); returns true when this knot is settled
     auto schedule = [&](bool pd) -> bool {
       if (!pd) {
@@ -462,10 +496,10 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     {
       const double a0[3] = {A[0], A[1], A[2]}, z0[3] = {Z[0], Z[1], Z[2]}, a1[3] = {A[3], A[4], A[5]}, z1[3] = {Z[3], Z[4], Z[5]};
       const double a2[6] = {A[6], A[7], A[8], A[9], A[10], A[11]}, z2[6] = {Z[6], Z[7], Z[8], Z[9], Z[10], Z[11]};
-      rank1_bi_02x3(Qh, a0, z0);
-      rank1_bi_x3(Qh, a1, z1);
-      if constexpr (GRAV) rank1_bi_023x6(Qh, a2, z2);
-      else rank1_bi_23x6(Qh, a2, z2);
+      rank1_bi_02x3_nn(Qh, a0, z0);
+      rank1_bi_x3_nn(Qh, a1, z1);
+      if constexpr (GRAV) rank1_bi_023x6_nn(Qh, a2, z2);
+      else rank1_bi_23x6_nn(Qh, a2, z2);
     }
     // Q_xx on its way through LDS for the symmetrisation: written here, read back (transposed) a few hundred cycles
     // later -- behind the factorisation / the gradient term / the forward substitution, not in front of the next knot
@@ -494,84 +528,110 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #pragma unroll
       for (int r = 0; r < 12; r++) Qh[r] = hsym * (Qh[r] + T[r]);
     };
-    {
-      const bool pd = attempt();
-      if (act) done = schedule(pd);
-    }
-    STAMP(3)
-    if (!__all(done)) {
-      for (;;) {
-        if (!done) done = schedule(attempt());
-        if (__all(done)) break;
-      }
-    }
     // gradient term: ||Q_u|| = ||D G|| in the MS vector lane, ||l_u + F_u^T p|| in the SS adjoint lane
-    {
-      double s = 0;
+    auto grad_term = [&](const double (&G)[M]) {
+      double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int u = 0; u < M; u++) { const double q = bu[u] * Y[u]; s = fma(q, q, s); }
+      for (int u = 0; u < M; u += 2) {
+        const double q0 = bu[u] * G[u], q1 = bu[u + 1] * G[u + 1];
+        s0 = fma(q0, q0, s0); s1 = fma(q1, q1, s1);
+      }
+      const double s_ = s0 + s1;
       // sqrt(s) = s rsqrt(s), v_rsq_f64 + one refinement step (4e-15 relative: the gradient norm is compared with 1e-6)
-      double y = __builtin_amdgcn_rsq(s);
-      { const double g_ = s * y, h_ = 0.5 * y; y = 2.0 * fma(h_, fma(-h_, g_, 0.5), h_); }
-      gsum += (s > 0.0) ? s * y : 0.0;
-    }
-    STAMP(4)
-    double zn[M], nri[M];
+      double y = __builtin_amdgcn_rsq(s_);
+      { const double g_ = s_ * y, h_ = 0.5 * y; y = 2.0 * fma(h_, fma(-h_, g_, 0.5), h_); }
+      gsum += (s_ > 0.0) ? s_ * y : 0.0;
+    };
+    // what follows a settled factorisation: forward substitution, V <- sym(Q_xx) - Y^T Dl^-1 Y (== Eq. 11b/11c of
+    // traopt_controller.py:2998-3004 for the exact gains), back substitution in place, gains [K | k] = D^-1 nx
+    auto finish = [&](double (&Y)[M], const double (&Uf)[M], double (&nri)[M]) {
+      grad_term(Y);
+      STAMP(4)
+      if (!ms) {  // the single-shooting adjoint lane takes no gain correction
 #pragma unroll
-    for (int u = 0; u < M; u++) nri[u] = -rinv[u];
-    if (!ms || __any(use_lu)) {  // the single-shooting adjoint lane takes no gain correction
-#pragma unroll
-      for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : nri[u];
-    }
-    if (__any(use_lu)) {
-      // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics (rare path).  Mt is rebuilt -- the
-      // factorisation ran in place -- replicated to every lane and solved by LU with partial pivoting; the value
-      // update takes the unfactored form V' = Q_xx - G^T x.
-      double Gk[M], Mc[M], Ac[M][M], Xl[M], X[M];
-      build(mu_used, Gk, Mc);
-#pragma unroll
-      for (int u = 0; u < M; u++) {
-        Xl[u] = Gk[u];
-#pragma unroll
-        for (int c = 0; c < M; c++) {
-          double v = 0;
-          if (c == 0) v = bcast<urow<M>(0)>(Mc[u]);
-          if (c == 1) v = bcast<urow<M>(1)>(Mc[u]);
-          if (c == 2) v = bcast<urow<M>(2)>(Mc[u]);
-          if (c == 3) v = bcast<urow<M>(3)>(Mc[u]);
-          if constexpr (M > 4) {
-            if (c == 4) v = bcast<urow<M>(4)>(Mc[u]);
-            if (c == 5) v = bcast<urow<M>(5)>(Mc[u]);
-          }
-          Ac[u][c] = v;
-        }
+        for (int u = 0; u < M; u++) nri[u] = (j == 13) ? 0.0 : nri[u];
       }
-      lu_solve<M>(Ac, Xl);
-      ldl3_forward<M>(Uf, nri, Y, zn);
-      ldl3_backward<M>(Uf, rinv, zn, X);
-      // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that the one rank-m update below serves both
-#pragma unroll
-      for (int u = 0; u < M; u++) {
-        const double xl = (j == 13) ? 0.0 : Xl[u];
-        Y[u] = use_lu ? Gk[u] : Y[u];
-        zn[u] = use_lu ? -xl : zn[u];
-        Kst[u] = -ibu[u] * (use_lu ? xl : X[u]);
-      }
-      symmetrise();
-      if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
-      else rank1_bi_x4(Qh, Y, zn);
-    } else {
-      // ---- Q_xx <- (Q_xx + Q_xx^T) / 2, V <- Qh - Y^T Dl^-1 Y (== Eq. 11b/11c of traopt_controller.py:2998-3004 for the
-      // exact gains), then the back substitution for the gains
+      double zn[M], nx[M];
       ldl3_forward<M>(Uf, nri, Y, zn);
       symmetrise();
       STAMP(5)
-      double X[M];
-      if constexpr (M == 6) rank1_bi_x6(Qh, Y, zn);
-      else rank1_bi_x4(Qh, Y, zn);
-      ldl3_backward<M>(Uf, rinv, zn, X);
+      if constexpr (M == 6) rank1_bi_x6_nn(Qh, Y, zn);
+      else rank1_bi_x4_nn(Qh, Y, zn);
+      ldl3_backward_nx<M>(Uf, nri, Y, zn, nx);
 #pragma unroll
-      for (int u = 0; u < M; u++) Kst[u] = -ibu[u] * X[u];
+      for (int u = 0; u < M; u++) Kst[u] = ibu[u] * nx[u];
+    };
+    // The first attempt and its tail are straight-line code on their own variables; retries and the max-regularisation
+    // exit (rare) run their own copy of the tail, so that the common path carries no merge copies.
+    {
+      double Y[M], Uf[M], nri[M], dv[M];
+      mu_used = mu;
+      build(mu, Y, Uf);
+      ldl3_factor<M>(Uf, nri, dv, wm);
+      const bool pd = ldl3_all_positive<M>(dv);
+      if (act) done = schedule(pd);
+      STAMP(3)
+      if (__all(done) && !__any(use_lu)) {
+        finish(Y, Uf, nri);
+      } else {
+        double Y2[M], U2[M], nr2[M], d2[M];
+#pragma unroll
+        for (int u = 0; u < M; u++) { Y2[u] = Y[u]; U2[u] = Uf[u]; nr2[u] = nri[u]; }
+        for (;;) {
+          if (__all(done)) break;
+          if (!done) {
+            mu_used = mu;
+            build(mu, Y2, U2);
+            ldl3_factor<M>(U2, nr2, d2, wm);
+            done = schedule(ldl3_all_positive<M>(d2));
+          }
+        }
+        if (!__any(use_lu)) {
+          finish(Y2, U2, nr2);
+        } else {
+          // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics.  Mt is rebuilt -- the factorisation
+          // ran in place -- replicated to every lane and solved by LU with partial pivoting; the value update takes the
+          // unfactored form V' = Q_xx - G^T x for those trajectories.
+          double Gk[M], Mc[M], Ac[M][M], Xl[M], zn[M], nx[M];
+          build(mu_used, Gk, Mc);
+          grad_term(Gk);
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            Xl[u] = Gk[u];
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+              double v = 0;
+              if (c == 0) v = bcast<urow<M>(0)>(Mc[u]);
+              if (c == 1) v = bcast<urow<M>(1)>(Mc[u]);
+              if (c == 2) v = bcast<urow<M>(2)>(Mc[u]);
+              if (c == 3) v = bcast<urow<M>(3)>(Mc[u]);
+              if constexpr (M > 4) {
+                if (c == 4) v = bcast<urow<M>(4)>(Mc[u]);
+                if (c == 5) v = bcast<urow<M>(5)>(Mc[u]);
+              }
+              Ac[u][c] = v;
+            }
+          }
+          lu_solve<M>(Ac, Xl);
+#pragma unroll
+          for (int u = 0; u < M; u++) nr2[u] = (j == 13) ? 0.0 : nr2[u];
+          ldl3_forward<M>(U2, nr2, Y2, zn);
+          // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that one rank-m update serves both kinds
+          double Yu[M];
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            const double xl = (j == 13) ? 0.0 : Xl[u];
+            Yu[u] = use_lu ? Gk[u] : Y2[u];
+            zn[u] = use_lu ? -xl : zn[u];
+          }
+          symmetrise();
+          if constexpr (M == 6) rank1_bi_x6(Qh, Yu, zn);
+          else rank1_bi_x4(Qh, Yu, zn);
+          ldl3_backward_nx<M>(U2, nr2, Y2, zn, nx);
+#pragma unroll
+          for (int u = 0; u < M; u++) Kst[u] = ibu[u] * (use_lu ? -((j == 13) ? 0.0 : Xl[u]) : nx[u]);
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 12; r++) V[r] = Qh[r];

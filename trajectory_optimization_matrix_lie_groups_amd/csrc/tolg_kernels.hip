@@ -889,465 +889,17 @@ TOLG_DEV void rank1_bk(double (&acc)[12], const double (&Pm)[12], double q) {
   if constexpr (K == 10) RANK1_BK(10);
   if constexpr (K == 11) RANK1_BK(11);
 }
-// ---- merged DPP blocks (machine-written: 36 / 18 / 72 fused multiply-adds per block): one hazard s_nop per block instead of one per row
-TOLG_DEV void rank1_bk3_0(double (&acc)[12], const double (&Pm)[12], double q0, double q1, double q2) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %24 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %25 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %26 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(Pm[6]), "v"(Pm[7]), "v"(Pm[8]), "v"(Pm[9]), "v"(Pm[10]), "v"(Pm[11]), "v"(q0), "v"(q1), "v"(q2));
-}
-TOLG_DEV void rank1_bk3_3(double (&acc)[12], const double (&Pm)[12], double q0, double q1, double q2) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(Pm[6]), "v"(Pm[7]), "v"(Pm[8]), "v"(Pm[9]), "v"(Pm[10]), "v"(Pm[11]), "v"(q0), "v"(q1), "v"(q2));
-}
-TOLG_DEV void rank1_bk3_6(double (&acc)[12], const double (&Pm)[12], double q0, double q1, double q2) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %26 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(Pm[6]), "v"(Pm[7]), "v"(Pm[8]), "v"(Pm[9]), "v"(Pm[10]), "v"(Pm[11]), "v"(q0), "v"(q1), "v"(q2));
-}
-TOLG_DEV void rank1_bk3_9(double (&acc)[12], const double (&Pm)[12], double q0, double q1, double q2) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %24 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %25 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %21, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %23, %26 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(Pm[0]), "v"(Pm[1]), "v"(Pm[2]), "v"(Pm[3]), "v"(Pm[4]), "v"(Pm[5]), "v"(Pm[6]), "v"(Pm[7]), "v"(Pm[8]), "v"(Pm[9]), "v"(Pm[10]), "v"(Pm[11]), "v"(q0), "v"(q1), "v"(q2));
-}
-TOLG_DEV void rank1_bi_02x3(double (&acc)[12], const double (&p)[3], const double (&q)[3]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %6, %7 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %6, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %6, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %6, %7 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %6, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %6, %7 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %8, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %10, %11 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %10, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %10, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %10, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %10, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %10, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]));
-}
-TOLG_DEV void rank1_bi_x3(double (&acc)[12], const double (&p)[3], const double (&q)[3]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %12, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %12, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %12, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %12, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %12, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %12, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %12, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %12, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %12, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %12, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %12, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %14, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %14, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %14, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %14, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %14, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %14, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %14, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %14, %15 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %14, %15 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %14, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %14, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]));
-}
-TOLG_DEV void rank1_bi_23x6(double (&acc)[12], const double (&p)[6], const double (&q)[6]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %6, %7 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %6, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %6, %7 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %6, %7 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %6, %7 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %6, %7 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %8, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %8, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %8, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %8, %9 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %10, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %10, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %10, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %10, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %10, %11 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %10, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %12, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %12, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %12, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %12, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %12, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %12, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %14, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %14, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %15 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %14, %15 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %14, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %14, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]), "v"(p[3]), "v"(q[3]), "v"(p[4]), "v"(q[4]), "v"(p[5]), "v"(q[5]));
-}
-TOLG_DEV void rank1_bi_023x6(double (&acc)[12], const double (&p)[6], const double (&q)[6]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %9, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %9, %10 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %9, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %9, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %9, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %9, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %9, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %9, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %9, %10 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %11, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %11, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %11, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %11, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %11, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %11, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %11, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %11, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %11, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %13, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %13, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %13, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %13, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %13, %14 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %13, %14 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %13, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %13, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %13, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %15, %16 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %15, %16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %15, %16 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %15, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %15, %16 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %15, %16 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %15, %16 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %15, %16 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %15, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %17, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %17, %18 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %17, %18 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %17, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %17, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %17, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %17, %18 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %17, %18 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %17, %18 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %19, %20 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %19, %20 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %19, %20 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %19, %20 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %19, %20 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %19, %20 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %19, %20 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %19, %20 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %19, %20 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]), "v"(p[3]), "v"(q[3]), "v"(p[4]), "v"(q[4]), "v"(p[5]), "v"(q[5]));
-}
-TOLG_DEV void rank1_bi_x6(double (&acc)[12], const double (&p)[6], const double (&q)[6]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %12, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %12, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %12, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %12, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %12, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %12, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %12, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %12, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %12, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %12, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %12, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %14, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %14, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %14, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %14, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %14, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %14, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %14, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %14, %15 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %14, %15 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %14, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %14, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %18, %19 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %18, %19 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %18, %19 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %18, %19 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %18, %19 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %18, %19 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %19 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %18, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %18, %19 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %18, %19 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %18, %19 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %18, %19 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %20, %21 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %20, %21 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %20, %21 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %20, %21 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %20, %21 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %20, %21 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %20, %21 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %20, %21 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %20, %21 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %20, %21 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %20, %21 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %20, %21 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %22, %23 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %22, %23 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %22, %23 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %22, %23 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %22, %23 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %22, %23 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %22, %23 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %22, %23 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %22, %23 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %22, %23 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %22, %23 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %22, %23 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]), "v"(p[3]), "v"(q[3]), "v"(p[4]), "v"(q[4]), "v"(p[5]), "v"(q[5]));
-}
-TOLG_DEV void rank1_bi_x4(double (&acc)[12], const double (&p)[4], const double (&q)[4]) {
-  asm volatile("s_nop 1\n\t"
-               "v_fmac_f64_dpp %0, %12, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %12, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %12, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %12, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %12, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %12, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %12, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %12, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %12, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %12, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %12, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %12, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %14, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %14, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %14, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %14, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %14, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %14, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %14, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %14, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %14, %15 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %14, %15 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %14, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %14, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %0, %18, %19 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %1, %18, %19 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %2, %18, %19 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %3, %18, %19 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %4, %18, %19 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %5, %18, %19 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %6, %18, %19 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %7, %18, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %8, %18, %19 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %9, %18, %19 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %10, %18, %19 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-               "v_fmac_f64_dpp %11, %18, %19 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-               : "v"(p[0]), "v"(q[0]), "v"(p[1]), "v"(q[1]), "v"(p[2]), "v"(q[2]), "v"(p[3]), "v"(q[3]));
-}
+// ---- merged DPP blocks: tolg_dpp_blocks.h, with and without the leading hazard s_nop
+#define TOLG_BLK(n) n
+#define TOLG_BLK_NOP "s_nop 1\n\t"
+#include "tolg_dpp_blocks.h"
+#undef TOLG_BLK
+#undef TOLG_BLK_NOP
+#define TOLG_BLK(n) n##_nn
+#define TOLG_BLK_NOP ""
+#include "tolg_dpp_blocks.h"
+#undef TOLG_BLK
+#undef TOLG_BLK_NOP
 #endif
 
 // x of the lane six to the right in the same 16-lane row (0 past the row end).  64-bit DPP exists only for
@@ -1424,6 +976,16 @@ TOLG_DEV void rank1_bi_23x6(double (&a)[12], const double (&p)[6], const double 
 TOLG_DEV void rank1_bi_023x6(double (&a)[12], const double (&p)[6], const double (&q)[6]) { for (int k = 0; k < 6; k++) rank1_bi_023(a, p[k], q[k]); }
 TOLG_DEV void rank1_bi_x6(double (&a)[12], const double (&p)[6], const double (&q)[6]) { for (int k = 0; k < 6; k++) rank1_bi(a, p[k], q[k]); }
 TOLG_DEV void rank1_bi_x4(double (&a)[12], const double (&p)[4], const double (&q)[4]) { for (int k = 0; k < 4; k++) rank1_bi(a, p[k], q[k]); }
+#define rank1_bk3_0_nn rank1_bk3_0
+#define rank1_bk3_3_nn rank1_bk3_3
+#define rank1_bk3_6_nn rank1_bk3_6
+#define rank1_bk3_9_nn rank1_bk3_9
+#define rank1_bi_02x3_nn rank1_bi_02x3
+#define rank1_bi_x3_nn rank1_bi_x3
+#define rank1_bi_23x6_nn rank1_bi_23x6
+#define rank1_bi_023x6_nn rank1_bi_023x6
+#define rank1_bi_x6_nn rank1_bi_x6
+#define rank1_bi_x4_nn rank1_bi_x4
 #endif
 
 // Cholesky of the symmetric part of Q (in place: on return the lower triangle of Q holds L with the
