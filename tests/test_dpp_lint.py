@@ -1,0 +1,54 @@
+"""The DPP read-after-VALU-write lint (trajectory_optimization_matrix_lie_groups_amd/_dpp_lint.py): the rule on synthetic
+disassembly, and the in-tree library clean (the backward sweep's inline-asm DPP blocks carry no blanket hazard nops)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajectory_optimization_matrix_lie_groups_amd import _build, _dpp_lint  # noqa: E402
+
+HEAD = "0000000000001000 <k>:\n"
+DPP = "\tv_fmac_f64_dpp v[10:11], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf// 000000001%03X: 0\n"
+
+
+def _ins(text, addr):
+    return "\t%s // 000000001%03X: 0\n" % (text, addr)
+
+
+@pytest.mark.parametrize("between, n_findings", [
+    ([], 1),                                            # writer directly in front
+    (["v_mul_f64 v[20:21], v[22:23], v[24:25]"], 1),   # one wait state
+    (["v_mul_f64 v[20:21], v[22:23], v[24:25]", "v_add_f64 v[30:31], v[22:23], v[24:25]"], 0),
+    (["s_nop 0"], 1),
+    (["s_nop 1"], 0),
+    (["s_nop 0", "s_waitcnt lgkmcnt(0)"], 0),
+])
+def test_rule_on_synthetic_disassembly(between, n_findings):
+    for writer in ("v_add_f64 v[4:5], v[0:1], v[2:3]", "v_accvgpr_read_b32 v5, a7"):
+        t, a = HEAD + _ins(writer, 0), 8
+        for b in between:
+            t += _ins(b, a); a += 8
+        t += DPP % a
+        assert len(_dpp_lint.lint(t)) == n_findings, (writer, between)
+    # a writer of an unrelated register, and the non-DPP operands, are no hazard
+    t = HEAD + _ins("v_add_f64 v[6:7], v[0:1], v[2:3]", 0) + DPP % 8
+    assert _dpp_lint.lint(t) == []
+
+
+def test_branch_target_in_window_is_reported():
+    t = HEAD + _ins("s_cbranch_execz 2 ", 0).replace("//", "// 0 <k+0x10>") + _ins("v_add_f64 v[30:31], v[0:1], v[2:3]", 8) + DPP % 0x10
+    assert any("branch target" in f[2] for f in _dpp_lint.lint(t))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(_dpp_lint.LLVM, "llvm-objdump")), reason="no llvm-objdump")
+def test_in_tree_library_has_no_dpp_hazard():
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build_extension()
+    lib = _build._SO
+    assert os.path.exists(lib)
+    text = _dpp_lint.disassemble(lib)
+    assert text.count("_dpp") > 1000  # the blocks are there
+    assert _dpp_lint.lint(text) == []

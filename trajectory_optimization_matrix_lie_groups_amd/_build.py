@@ -60,7 +60,7 @@ def _git_head():
         return None
 
 
-def build_extension(force=False, verbose=False, extra_flags=()):
+def build_extension(force=False, verbose=False, extra_flags=(), lint=True):
     """hipcc --offload-arch=gfx950 -> trajectory_optimization_matrix_lie_groups_amd/libtolg_hip.so"""
     if not force and not _stale():
         return _SO
@@ -71,6 +71,15 @@ def build_extension(force=False, verbose=False, extra_flags=()):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if lint:
+        # the hand-written DPP blocks run without hazard nops where the emitted code keeps the distance: check that it does
+        from . import _dpp_lint
+        findings = _dpp_lint.lint(_dpp_lint.disassemble(_SO))
+        if findings:
+            bad = _SO + ".hazard"
+            os.replace(_SO, bad)
+            raise RuntimeError("DPP read-after-write hazards in the built library (kept as %s):\n%s"
+                               % (bad, "\n".join("%s %x: %s" % f for f in findings[:20])))
     with open(_INFO, "w") as f:
         json.dump({"source_sha256_16": source_hash(), "git_head": _git_head(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%S"),
                    "flags": list(extra_flags)}, f)

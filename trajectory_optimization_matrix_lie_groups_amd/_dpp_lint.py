@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""DPP read-after-VALU-write lint over the built library's gfx950 code.
+
+The backward sweep's products are hand-written `v_fmac_f64_dpp` / `v_mov_b64_dpp` blocks (inline asm).  CDNA has no
+interlock for "VALU writes a VGPR, a DPP instruction reads it as its DPP operand (src0) within the next two wait
+states": the read returns the old value.  The compiler pads its own DPP instructions; it does not look into inline
+asm, and it is free to schedule the instruction that produces an asm operand (an add, a copy, a v_accvgpr_read)
+directly in front of the block.  Most blocks here run without a leading s_nop (the sweep is issue-bound and an
+s_nop costs as much as a multiply-add, profiles/r03_valu_issue_microbench.txt), which is only sound if the code the
+compiler actually emitted keeps the distance -- so this lint checks exactly that, on every build:
+
+    for every DPP instruction: none of the instructions in the two wait states in front of it (program order, s_nop N
+    counting N + 1) is a VALU instruction that writes a register of the DPP operand.
+
+A branch target inside the window is reported as well (the other predecessor cannot be seen in a linear scan).
+
+    python tools/dpp_hazard_lint.py [path/to/libtolg_hip.so]      exit code 1 on a finding
+
+`_build.build_extension` runs it on every build and refuses a library with findings; tests/test_dpp_lint.py runs it on
+the in-tree library.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def disassemble(lib):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "null")])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--targets={TARGET}",
+                               f"--output={co}"])
+        return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co]).decode()
+
+
+_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _regs(tok):
+    out = set()
+    for m in _REG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def _is_valu(op):
+    return op.startswith("v_") and not op.startswith("v_nop")
+
+
+def lint(text):
+    """-> list of (kernel, address, message)"""
+    findings = []
+    kernel = None
+    window = []  # (wait_states, opcode, written regs, address, is_label)
+    targets = set()
+    lines = text.splitlines()
+    # branch targets: objdump prints them as <symbol+0xOFF> in the comment of the branch
+    for ln in lines:
+        m = re.search(r"s_c?branch\S*\s.*<([^>+]+)\+0x([0-9a-f]+)>", ln)
+        if m:
+            targets.add((m.group(1), int(m.group(2), 16)))
+    base = 0
+    for ln in lines:
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
+        if m:
+            kernel, base, window = m.group(2), int(m.group(1), 16), []
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+        if not m or kernel is None:
+            continue
+        op, args, addr = m.group(1), m.group(2), int(m.group(3), 16)
+        is_target = (kernel, addr - base) in targets
+        if is_target:
+            window.append((0, "<label>", set(), addr, True))
+        if "row_newbcast" in args or "row_shl" in args or "row_shr" in args or "quad_perm" in args or "row_bcast" in args \
+                or "row_ror" in args or "row_mirror" in args or "wave_" in args or "row_half_mirror" in args or op.endswith("_dpp"):
+            toks = [t.strip() for t in args.split(",")]
+            # src0 is the DPP operand: the second token (after the destination)
+            src0 = _regs(toks[1].split()[0]) if len(toks) > 1 else set()
+            ws = 0
+            for w_ws, w_op, w_regs, w_addr, w_label in reversed(window):
+                if ws >= 2:
+                    break
+                if w_label:
+                    findings.append((kernel, addr, "branch target %d wait state(s) in front of %s (DPP operand v%s)" % (ws, op, sorted(src0))))
+                    continue
+                if _is_valu(w_op) and (w_regs & src0):
+                    findings.append((kernel, addr, "%s reads v%s through DPP %d wait state(s) after %s at %x wrote it"
+                                     % (op, sorted(w_regs & src0), ws, w_op, w_addr)))
+                ws += w_ws
+        # record this instruction
+        if op == "s_nop":
+            n = int(args.split()[0], 0) if args else 0
+            window.append((n + 1, op, set(), addr, False))
+        else:
+            toks = [t.strip() for t in args.split(",")]
+            written = _regs(toks[0]) if toks and _is_valu(op) and not op.startswith("v_cmp") else set()
+            if op.startswith("v_accvgpr_write"):
+                written = set()
+            window.append((1, op, written, addr, False))
+        if len(window) > 8:
+            window = window[-8:]
+    return findings
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtolg_hip.so")
+    f = lint(disassemble(lib))
+    for k, a, msg in f:
+        print("%s  %x: %s" % (k, a, msg))
+    print("%d finding(s) in %s" % (len(f), lib))
+    return 1 if f else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

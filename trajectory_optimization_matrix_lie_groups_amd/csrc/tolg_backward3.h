@@ -37,6 +37,16 @@ __host__ __device__ constexpr int urow(int u) { return (u < 3 || M == 6) ? 6 + u
 template <int M, int J, int LN>
 TOLG_DEV void ldl3_update(double (&a)[M], double w) {
   constexpr int R = M - 1 - J;
+  // Pivot 0: the columns come straight from compiler-scheduled code, which may place the instruction that writes one
+  // of them directly in front of the block (a VALU write needs two wait states before a DPP read; nothing interlocks).
+  // The nop takes the columns as operands so that their producers cannot sink below it.  Later pivots read what the
+  // previous update block wrote, several instructions back in program order.
+  if constexpr (J == 0) {
+    if constexpr (M == 6)
+      asm volatile("s_nop 1" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+    else
+      asm volatile("s_nop 1" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+  }
   if constexpr (R == 5)
     asm volatile(DF3("%0", "%0", "%5", "%6") DF3("%1", "%1", "%5", "%6") DF3("%2", "%2", "%5", "%6")
                      DF3("%3", "%3", "%5", "%6") DF3("%4", "%4", "%5", "%6")
@@ -57,8 +67,10 @@ TOLG_DEV void ldl3_update(double (&a)[M], double w) {
 // y += sum_{k < I} p@lane urow(k) * q[k]  (row I of the forward substitution; p = this lane's a[I])
 template <int M, int I>
 TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
+  // (row 1 opens the substitution: its column may have just come back from an AGPR -- tools/dpp_hazard_lint.py found
+  // exactly that -- so it carries the two wait states itself)
   if constexpr (I == 1)
-    asm volatile(DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
   if constexpr (I == 2)
     asm volatile(DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0)), "n"(urow<M>(1)));
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     double Z[12];
 #pragma unroll
     for (int r = 0; r < 12; r++) Z[r] = (1.0 - m12) * V[r];
-    rank1_bk3_0_nn(Z, V, A[0], A[1], A[2]); rank1_bk3_3_nn(Z, V, A[3], A[4], A[5]);
+    rank1_bk3_0(Z, V, A[0], A[1], A[2]); rank1_bk3_3_nn(Z, V, A[3], A[4], A[5]);
     {  // velocity block of F_x on top of its identity column (lanes 6..11; every constant is zero elsewhere); here, behind
       // the first half of the product, its LDS reads have long returned
       const double eA0 = fma(c0.x, xB.x, c0.y * xB.y), eB0 = fma(c1.x, xA.x, c1.y * xA.y), eA1 = c2.x * xB.y, eB1 = c2.y * xA.y;
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // ---- Qh = [l_xx | l_x] + F_x^T Z   (F_x = [Ri 0 Jr 0; TRi Ri Qr Jr; A21 0 A22 A22]: zero 3-row blocks skipped)
 #pragma unroll
     for (int r = 0; r < 6; r++) Qh[6 + r] += kBW[r];
-    bool done = true;
+    bool done = !act;  // (general path) inactive trajectories are settled from the start
     {
       const double a0[3] = {A[0], A[1], A[2]}, z0[3] = {Z[0], Z[1], Z[2]}, a1[3] = {A[3], A[4], A[5]}, z1[3] = {Z[3], Z[4], Z[5]};
       const double a2[6] = {A[6], A[7], A[8], A[9], A[10], A[11]}, z2[6] = {Z[6], Z[7], Z[8], Z[9], Z[10], Z[11]};
@@ -561,76 +573,90 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #pragma unroll
       for (int u = 0; u < M; u++) Kst[u] = ibu[u] * nx[u];
     };
-    // The first attempt and its tail are straight-line code on their own variables; retries and the max-regularisation
-    // exit (rare) run their own copy of the tail, so that the common path carries no merge copies.
-    {
+    // The common case -- no regularisation left (mu decays to 0 within the first six knots of a solve and stays there),
+    // first attempt positive definite for every trajectory of the wave -- is straight-line code on its own variables:
+    // no mu terms, no merge copies.  Everything else (mu != 0, a failed attempt, the max-regularisation exit) takes
+    // the general path below, which starts the knot's attempts from scratch.
+    bool settled = false;
+#ifdef TOLG_K3_NOFAST
+    if (false) {
+#else
+    if (!__any(act && mu != 0.0)) {
+#endif
       double Y[M], Uf[M], nri[M], dv[M];
-      mu_used = mu;
-      build(mu, Y, Uf);
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        Y[u] = fma(lu[u], ibu[u], Z[urow<M>(u)]);
+        Uf[u] = V[urow<M>(u)] + Rt[u];
+        if constexpr (al) Uf[u] += (mycol == u) ? luu_i * ibu[u] * ibu[u] : 0.0;
+      }
       ldl3_factor<M>(Uf, nri, dv, wm);
       const bool pd = ldl3_all_positive<M>(dv);
-      if (act) done = schedule(pd);
       STAMP(3)
-      if (__all(done) && !__any(use_lu)) {
+      if (!__any(act && !pd)) {
+        if (act) { delta = fmin(1.0, delta) * 0.5; mu = 0.0; }  // schedule(true) with mu == 0 (:2986-2991)
         finish(Y, Uf, nri);
+        settled = true;
+      }
+    }
+    if (!settled) {
+      double Y2[M], U2[M], nr2[M], d2[M];
+      for (;;) {
+        if (!done) {
+          mu_used = mu;
+          build(mu, Y2, U2);
+          ldl3_factor<M>(U2, nr2, d2, wm);
+          done = schedule(ldl3_all_positive<M>(d2));
+        }
+        if (__all(done)) break;
+      }
+      // every lane: the factorisation of its own settled attempt (a lane that settled early sat out the later rounds)
+      build(mu_used, Y2, U2);
+      ldl3_factor<M>(U2, nr2, d2, wm);
+      if (!__any(use_lu)) {
+        finish(Y2, U2, nr2);
       } else {
-        double Y2[M], U2[M], nr2[M], d2[M];
+        // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics.  Mt is rebuilt -- the factorisation
+        // ran in place -- replicated to every lane and solved by LU with partial pivoting; the value update takes the
+        // unfactored form V' = Q_xx - G^T x for those trajectories.
+        double Gk[M], Mc[M], Ac[M][M], Xl[M], zn[M], nx[M];
+        build(mu_used, Gk, Mc);
+        grad_term(Gk);
 #pragma unroll
-        for (int u = 0; u < M; u++) { Y2[u] = Y[u]; U2[u] = Uf[u]; nr2[u] = nri[u]; }
-        for (;;) {
-          if (__all(done)) break;
-          if (!done) {
-            mu_used = mu;
-            build(mu, Y2, U2);
-            ldl3_factor<M>(U2, nr2, d2, wm);
-            done = schedule(ldl3_all_positive<M>(d2));
-          }
-        }
-        if (!__any(use_lu)) {
-          finish(Y2, U2, nr2);
-        } else {
-          // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics.  Mt is rebuilt -- the factorisation
-          // ran in place -- replicated to every lane and solved by LU with partial pivoting; the value update takes the
-          // unfactored form V' = Q_xx - G^T x for those trajectories.
-          double Gk[M], Mc[M], Ac[M][M], Xl[M], zn[M], nx[M];
-          build(mu_used, Gk, Mc);
-          grad_term(Gk);
+        for (int u = 0; u < M; u++) {
+          Xl[u] = Gk[u];
 #pragma unroll
-          for (int u = 0; u < M; u++) {
-            Xl[u] = Gk[u];
-#pragma unroll
-            for (int c = 0; c < M; c++) {
-              double v = 0;
-              if (c == 0) v = bcast<urow<M>(0)>(Mc[u]);
-              if (c == 1) v = bcast<urow<M>(1)>(Mc[u]);
-              if (c == 2) v = bcast<urow<M>(2)>(Mc[u]);
-              if (c == 3) v = bcast<urow<M>(3)>(Mc[u]);
-              if constexpr (M > 4) {
-                if (c == 4) v = bcast<urow<M>(4)>(Mc[u]);
-                if (c == 5) v = bcast<urow<M>(5)>(Mc[u]);
-              }
-              Ac[u][c] = v;
+          for (int c = 0; c < M; c++) {
+            double v = 0;
+            if (c == 0) v = bcast<urow<M>(0)>(Mc[u]);
+            if (c == 1) v = bcast<urow<M>(1)>(Mc[u]);
+            if (c == 2) v = bcast<urow<M>(2)>(Mc[u]);
+            if (c == 3) v = bcast<urow<M>(3)>(Mc[u]);
+            if constexpr (M > 4) {
+              if (c == 4) v = bcast<urow<M>(4)>(Mc[u]);
+              if (c == 5) v = bcast<urow<M>(5)>(Mc[u]);
             }
+            Ac[u][c] = v;
           }
-          lu_solve<M>(Ac, Xl);
-#pragma unroll
-          for (int u = 0; u < M; u++) nr2[u] = (j == 13) ? 0.0 : nr2[u];
-          ldl3_forward<M>(U2, nr2, Y2, zn);
-          // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that one rank-m update serves both kinds
-          double Yu[M];
-#pragma unroll
-          for (int u = 0; u < M; u++) {
-            const double xl = (j == 13) ? 0.0 : Xl[u];
-            Yu[u] = use_lu ? Gk[u] : Y2[u];
-            zn[u] = use_lu ? -xl : zn[u];
-          }
-          symmetrise();
-          if constexpr (M == 6) rank1_bi_x6(Qh, Yu, zn);
-          else rank1_bi_x4(Qh, Yu, zn);
-          ldl3_backward_nx<M>(U2, nr2, Y2, zn, nx);
-#pragma unroll
-          for (int u = 0; u < M; u++) Kst[u] = ibu[u] * (use_lu ? -((j == 13) ? 0.0 : Xl[u]) : nx[u]);
         }
+        lu_solve<M>(Ac, Xl);
+#pragma unroll
+        for (int u = 0; u < M; u++) nr2[u] = (j == 13) ? 0.0 : nr2[u];
+        ldl3_forward<M>(U2, nr2, Y2, zn);
+        // lanes of a max-regularised trajectory: (Y, zn) <- (G, -x) so that one rank-m update serves both kinds
+        double Yu[M];
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          const double xl = (j == 13) ? 0.0 : Xl[u];
+          Yu[u] = use_lu ? Gk[u] : Y2[u];
+          zn[u] = use_lu ? -xl : zn[u];
+        }
+        symmetrise();
+        if constexpr (M == 6) rank1_bi_x6(Qh, Yu, zn);
+        else rank1_bi_x4(Qh, Yu, zn);
+        ldl3_backward_nx<M>(U2, nr2, Y2, zn, nx);
+#pragma unroll
+        for (int u = 0; u < M; u++) Kst[u] = ibu[u] * (use_lu ? -((j == 13) ? 0.0 : Xl[u]) : nx[u]);
       }
     }
 #pragma unroll
