@@ -94,9 +94,41 @@ def test_generic_loop_matches_the_oracle_solver(kind, mode):
         assert defect_hist[0] == pytest.approx(o["defect_hist"][0], rel=1e-10)
 
 
-def test_merit_search_is_fused_only():
-    prob, *_ = workloads.se3_tracking(1, N=5)
+@pytest.mark.parametrize("kind, R_scale, noise, rollout", [("se3", 1e-6, 5.0, "nonlinear"), ("se3", 1e-6, 5.0, "linear"),
+                                                            ("drone", 1e-3, 50.0, "nonlinear")])
+def test_generic_merit_line_search_matches_the_oracle(kind, R_scale, noise, rollout):
+    """MS with line_search=True on the plugin path: defect weight, merit and Armijo test of
+    traopt_controller.py:2549-2590, against the oracle's restatement of the same loop.  The starts are chosen so
+    that the search backtracks (se3: alpha = 1.1^-4 at iteration 2) or exhausts its 20 step sizes and stops with
+    the reference's warning (drone, iteration 2)."""
+    N, K = 16, 8
+    f = workloads.drone_tracking if kind == "drone" else workloads.se3_tracking
+    prob, x0_q, x0_xi, us0 = f(1, N=N, R_scale=R_scale)
+    rng = np.random.default_rng(3)
+    us0 = us0 + noise * rng.normal(size=us0.shape)
+    x0_xi = x0_xi + 2.0 * rng.normal(size=x0_xi.shape)
     op = ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
-    ctl = iLQR_Tracking_SE3_MS(MyDynamics(op, 6), MyCost(op, 6), 5, prob.q_ref, prob.xi_ref, line_search=True)
-    with pytest.raises(NotImplementedError):
-        ctl.fit([prob.q_ref[0], prob.xi_ref[0]], np.zeros((5, 6)))
+    alphas, acc = [], []
+
+    def cb(*a):
+        a[-5].append(a[3])
+        alphas.append(a[8]); acc.append(a[4])
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ctl = iLQR_Tracking_SE3_MS(MyDynamics(op, prob.m), MyCost(op, prob.m), N, prob.q_ref, prob.xi_ref, line_search=True,
+                                   rollout=rollout)
+        xs, us, J_hist, _, _, _, _ = ctl.fit([x0_q[0], x0_xi[0]], us0[0], n_iterations=K, tol_grad_norm=0.0, on_iteration=cb)
+        o = ob.fit(op, x0_q[0], x0_xi[0], us0[0], mode="ms", max_iter=K, tol_grad=0.0, line_search=True, rollout=rollout)
+    n = int(o["n_iters"])
+    assert len(J_hist) == n
+    assert np.allclose(J_hist, o["J_hist"][:n], rtol=1e-9)
+    ok = np.array(acc, bool)
+    assert np.allclose(np.array(alphas)[ok], o["alpha_hist"][:n][ok])
+    assert min(alphas) < 1.0
+    if kind == "drone":
+        assert not ok[-1] and n < K and any("descent direction" in str(x.message) for x in w)
+    else:
+        assert ok.all() and n == K
+    assert np.abs(us - o["us"]).max() < 1e-7 * max(1.0, np.abs(o["us"]).max())
+    assert np.abs(np.stack([x[0] for x in xs]) - o["xs_q"]).max() < 1e-8

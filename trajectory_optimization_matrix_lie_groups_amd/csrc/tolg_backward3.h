@@ -461,10 +461,18 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // records of knot i - 2 come into this slot.  Stores first: the wait at the top of a step covers both, in order.
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TOLG_STAMPS2  // finer split of this phase: (1) ends behind the wait, (2) is the gain stores alone, the DMA issue counts into (3)
+    STAMP(1)
+#endif
     if (i < N - 1) store_gains(i + 1);
+#ifdef TOLG_STAMPS2
+    STAMP(2)
+#endif
     if (i >= 2) dma_knot(i - 2, SLOT);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef TOLG_STAMPS2
     STAMP(2)
+#endif
     // ---- regularised G = rows S of (V + mu I)[F_x | d] (+ D^-1 l_u in the vector columns), Mt; PD test
     // (traopt_controller.py:2964-2995, :3052-3060)
     bool use_lu = false;

@@ -47,12 +47,10 @@ class GenericLieILQR:
     """mode 'ms' / 'ss'; the public controllers keep the reference's signatures and delegate here."""
 
     def __init__(self, dynamics, cost, N, mode, max_reg=1e10, line_search=False, rollout="nonlinear"):
-        if mode == "ms" and line_search:
-            raise NotImplementedError("the merit-function search exists on the fused path only "
-                                      "(closed-form dynamics / cost classes)")
         self.dynamics, self.cost, self.N, self.mode = dynamics, cost, int(N), mode
         self.n, self.m = 12, int(dynamics.action_size)
         self.max_reg, self.linear = max_reg, rollout == "linear"
+        self.merit = mode == "ms" and bool(line_search)   # merit-function search (traopt_controller.py:2549-2590)
         self.mu, self.delta = 1.0, 2.0
 
     # ---- one pass over the plugins ---------------------------------------------------------------
@@ -131,17 +129,21 @@ class GenericLieILQR:
             V[:n, :n] = 0.5 * (V[:n, :n] + V[:n, :n].T)
         return k, K, gsum / N, warned
 
-    def _rollout(self, xs, us, k, K, e, alpha):
+    def _rollout(self, xs, us, k, K, e, alpha, linear=None, errs=None):
+        """`errs` (a dict) receives the deviations dx [N+1, n], du [N, m] of the new path from the nominal one."""
         n, m, N, ms = self.n, self.m, self.N, self.mode == "ms"
+        linear = self.linear if linear is None else linear
         xs_new = [[np.array(xs[0][0], float), np.array(xs[0][1], float)]]
         us_new = np.zeros_like(us)
+        dxs, dus = np.zeros((N + 1, n)), np.zeros((N, m))
         for i in range(N):
             dx = _dev(xs[i], xs_new[i])
             du = alpha * k[i] + K[i] @ dx
+            dxs[i], dus[i] = dx, du
             us_new[i] = us[i] + du
             G = e["G"][i]
             d = G[:n, n + m]
-            if self.linear:   # :2720-2726: x_{i+1} (+) (F_x dx + F_u du + alpha d)
+            if linear:        # :2720-2726: x_{i+1} (+) (F_x dx + F_u du + alpha d)
                 lin = G[:n, :n] @ dx + G[:n, n:n + m] @ du + alpha * d
                 base = xs[i + 1]
                 q = _project(np.asarray(base[0], float) @ _exp(lin[:6]))
@@ -154,7 +156,23 @@ class GenericLieILQR:
                 else:         # :2073-2080
                     q, xi = np.asarray(fq, float), np.asarray(fxi, float)
             xs_new.append([q, xi])
+        if errs is not None:
+            dxs[N] = _dev(xs[N], xs_new[N])
+            errs["dx"], errs["du"] = dxs, dus
         return xs_new, us_new
+
+    def _expected_cost_change(self, e, dxs, dus):
+        """(first order, second order) of the quadratic cost model along the deviations (:2756-2769)."""
+        n, m, N = self.n, self.m, self.N
+        c1 = c2 = 0.0
+        for i in range(N):
+            z = np.r_[dxs[i], dus[i]]
+            Hi = e["H"][i]
+            c1 += float(Hi[:n + m, n + m] @ z)
+            c2 += float(z @ Hi[:n + m, :n + m] @ z)
+        c1 += float(e["HN"][:n, n] @ dxs[N])
+        c2 += float(dxs[N] @ e["HN"][:n, :n] @ dxs[N])
+        return c1, c2
 
     def _cost_and_defect(self, xs, us):
         J = sum(float(self.cost.l(xs[i], us[i], i)) for i in range(self.N))
@@ -182,7 +200,9 @@ class GenericLieILQR:
                 fq, fxi = self.dynamics.f(xs[i], us[i], i)
                 xs.append([np.asarray(fq, float), np.asarray(fxi, float)])
         J_hist, xs_hist, us_hist, grad_hist, defect_hist = [], [list(xs)], [us.copy()], [], []
-        alphas = [1.0] if ms else list(1.1 ** (-np.arange(13) ** 2))
+        merit = self.merit
+        alphas = (list(1.1 ** (-np.arange(20) ** 2)) if merit else [1.0]) if ms else list(1.1 ** (-np.arange(13) ** 2))
+        d_weight_prev = 10.0   # _defect_mu0 (:2406-2410: rho 0.5, gamma 0.05, mu_min = mu0, kappa 1e-12)
         e = self._expand(xs, us)
         if ms:
             defect_hist.append(e["dnorm"])
@@ -195,10 +215,25 @@ class GenericLieILQR:
                     grad_hist.append(grad)
                 break
             accepted, J_opt, dn, alpha = False, e["J"], e["dnorm"], 1.0
+            if merit:
+                # expected change of the quadratic model along the full linear step, defect weight, merit (:2549-2558)
+                errs = {}
+                self._rollout(xs, us, k, K, e, 1.0, linear=True, errs=errs)
+                c1, c2 = self._expected_cost_change(e, errs["dx"], errs["du"])
+                d_norm = e["dnorm"]
+                d_weight = d_weight_prev if d_norm < 1e-12 else max(10.0, 10.0 + abs(c1 + 0.5 * c2) / ((1 - 0.5) * d_norm))
+                d_weight_prev = d_weight
+                merit0 = J_opt + d_weight * d_norm
             for alpha in alphas:
                 xs_try, us_try = self._rollout(xs, us, k, K, e, alpha)
                 J_try, d_try = self._cost_and_defect(xs_try, us_try)
-                if ms or J_try < J_opt:      # MS without line search accepts every step (:2593-2612)
+                if merit:                    # Armijo test on the merit function (:2560-2590)
+                    dn = d_try               # the callback sees the last candidate's defect norm, accepted or not
+                    J_exp = alpha * c1 + 0.5 * alpha ** 2 * c2
+                    if (J_try + d_weight * d_try) - merit0 < 0.05 * (J_exp - alpha * d_weight * d_norm):
+                        xs, us, J_opt, accepted = xs_try, us_try, J_try, True
+                        break
+                elif ms or J_try < J_opt:    # MS without line search accepts every step (:2593-2612)
                     xs, us, J_opt, dn, accepted = xs_try, us_try, J_try, d_try, True
                     break
             if accepted:
