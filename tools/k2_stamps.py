@@ -1,7 +1,12 @@
 """Per-phase cycle stamps of the backward sweep (debug build: hipcc ... -DTOLG_STAMPS, loaded through
 TOLG_HIP_LIB).  Prints s_memtime cycles per knot for each phase of k_backward3 (tolg_backward3.h), wavefront 7."""
+import os
+import sys
+
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR, workloads
 
 B, N, K = 4096, 200, 12

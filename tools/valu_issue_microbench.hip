@@ -47,6 +47,28 @@ template <int KIND, int DEP> void run(const char* name) {
   (void)hipMemcpy(h, g_cyc, sizeof h, hipMemcpyDeviceToHost);
   printf("%-22s %s: %.2f cycles per instruction\n", name, DEP ? "dependent  " : "independent", (double)h[3] / (reps * 32.0) / (KIND == 12 ? 2 : 1));
 }
+// the same instruction stream with W waves resident per SIMD (1024 W workgroups of one wave): cycles one wave takes per
+// instruction, and per SIMD (that / W) -- what a second resident wave buys an issue-bound kernel
+template <int KIND, int DEP> void run_occ(const char* name) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int W = 1; W <= 8; W *= 2) {
+    const int reps = 4000, blocks = 1024 * W;
+    hipLaunchKernelGGL((k<KIND, DEP>), dim3(blocks), dim3(64), 0, 0, g_out, g_cyc, g_in, reps);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<KIND, DEP>), dim3(blocks), dim3(64), 0, 0, g_out, g_cyc, g_in, reps);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[64];
+    (void)hipMemcpy(h, g_cyc, sizeof h, hipMemcpyDeviceToHost);
+    double m = 0;
+    for (int i = 0; i < 64; i++) m += (double)h[i] / 64;
+    printf("%-18s %s, %d wave(s) per SIMD: %.2f cycles per instruction and wave (s_memtime), kernel %.3f ms = %.2f ns per instruction and SIMD\n", name,
+           DEP ? "dependent  " : "independent", W, m / (reps * 32.0), ms, ms * 1e6 / (reps * 32.0) / W);
+  }
+}
 int main() {
   (void)hipMalloc(&g_in, 256 * 8); (void)hipMalloc(&g_out, 8192 * 64 * 8); (void)hipMalloc(&g_cyc, 8192 * 8);
   double h[256]; for (int i = 0; i < 256; i++) h[i] = 1.0 + (i % 7) * 0.01;
@@ -63,5 +85,6 @@ int main() {
   run<6, 0>("v_cvt_f32_f64"); run<7, 0>("v_cvt_f64_f32");
   run<10, 0>("v_cndmask_b32");
   run<12, 0>("v_accvgpr write+read");
+  run_occ<0, 0>("v_fma_f64"); run_occ<0, 1>("v_fma_f64"); run_occ<9, 0>("v_fmac_f64_dpp"); run_occ<9, 1>("v_fmac_f64_dpp");
   return 0;
 }

@@ -225,6 +225,9 @@ enum { B3_DATA = 5120, B3_ZBYTES = 256,
        B3_KC = B3_DUMP + 12 * B3_TRS * 8, B3_LDS = B3_KC + 16 * 16 * 8 };
 
 // AL: augmented-Lagrangian solve (the records carry the l_uu diagonal; decides the record size with M and GRAV).
+#ifndef TOLG_K3_X
+#define TOLG_K3_X 0
+#endif
 template <int M, bool GRAV, bool AL>
 __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
@@ -368,12 +371,20 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   int warned = 0;
 
   // one knot of records into LDS slot s (wave-uniform source, 16 bytes per lane and instruction)
-  auto dma_knot = [&](int i, int s) {
-    const char* src = reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes;
+  auto dma_from = [&](const char* src, int s) {
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)s * B3_SLOT));
     if constexpr (NKB == 3) rl_dma16x3(uniform_ptr(src), (unsigned)lane * 16u, dst);
     else rl_dma16x4(uniform_ptr(src), (unsigned)lane * 16u, dst);
   };
+  auto dma_knot = [&](int i, int s) {
+    dma_from(reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes, s);
+  };
+  // running addresses of the knot loop (one 64-bit subtraction per knot instead of the multiplications of the indexed
+  // form -- the wave issues its scalar instructions in line with the vector ones): the records of knot i - 2 and the
+  // gains of knot i + 1 at step i
+  const char* rec_run = reinterpret_cast<const char*>(P.REC + recStride * (size_t)(N > 2 ? N - 2 : 0)) + (size_t)blockIdx.x * blockBytes;
+  const double* gk_run = P.GK + gStride * (size_t)(N + 1);
+  const size_t recStrideB = recStride * 8;
 
   // terminal condition: V = [l_xx(N) | l_x(N)] with P weights (traopt_controller.py:2956-2957)
   double V[12];
@@ -393,9 +404,9 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   double Kst[M];
 #pragma unroll
   for (int u = 0; u < M; u++) Kst[u] = 0;
-  auto store_gains = [&](int knot) {
+  auto store_gains = [&](const double* gk) {
     if (act && j < 13) {
-      __amdgpu_buffer_rsrc_t rGs = mkbuf(P.GK + gStride * knot, 13 * M * sB);
+      __amdgpu_buffer_rsrc_t rGs = mkbuf(gk, 13 * M * sB);
 #pragma unroll
       for (int u = 0; u < M; u += 2) bst2(rGs, vG, GOFF(u, 0, M), Kst[u], Kst[u + 1]);
     }
@@ -416,8 +427,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // The records of knot i were requested two steps ago; the memory queue retires in order, so "everything but
     // the last step's gain stores and record request" is a counted wait.  (Step 0 is preceded by a step that
     // requested nothing.)
+#if TOLG_K3_X != 1  // (TOLG_K3_X: timing experiments that drop one piece of the step; results are wrong by construction)
     if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + NKB) : "memory");
+#endif
+    // (Fencing these reads into use order -- the six that open the Z product first, [l_xx | l_x] and l_u behind its first
+    // block -- was measured: +0.02 ms.  The compiler's order stays.)
     double A[12], Qh[12], lu[M], luu_i = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; r++) { A[r] = ld(oT[r]); A[3 + r] = ld(oM[r]); }
@@ -464,11 +479,17 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #ifdef TOLG_STAMPS2  // finer split of this phase: (1) ends behind the wait, (2) is the gain stores alone, the DMA issue counts into (3)
     STAMP(1)
 #endif
-    if (i < N - 1) store_gains(i + 1);
+    gk_run -= gStride;
+#if TOLG_K3_X != 2
+    if (i < N - 1) store_gains(gk_run);
+#endif
 #ifdef TOLG_STAMPS2
     STAMP(2)
 #endif
-    if (i >= 2) dma_knot(i - 2, SLOT);
+    rec_run -= recStrideB;
+#if TOLG_K3_X != 3
+    if (i >= 2) dma_from(rec_run, SLOT);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef TOLG_STAMPS2
     STAMP(2)
@@ -527,6 +548,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // factor of two knots (~1.2 measured, 4 at worst), which leaves it at rounding level.
 #ifdef TOLG_K3_SYM1
     constexpr bool SYM = true;
+#elif TOLG_K3_X == 4
+    constexpr bool SYM = false;
 #else
     constexpr bool SYM = SLOT == 0;
 #endif
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     step(i - 1, std::integral_constant<int, 1>());
   }
   if (i == 0) step(0, std::integral_constant<int, 0>());
-  store_gains(0);
+  store_gains(P.GK);
 #ifdef TOLG_STAMPS
   STAMP(7)
   if (blockIdx.x == 7 && lane == 0 && P.mu_hist) { for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st_acc[k]; }
