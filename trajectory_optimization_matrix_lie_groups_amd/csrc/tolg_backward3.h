@@ -65,28 +65,28 @@ TOLG_DEV void ldl3_update(double (&a)[M], double w) {
     asm volatile(DF3("%0", "%0", "%1", "%2") : "+v"(a[J + 1]) : "v"(w), "n"(LN));
 }
 // y += sum_{k < I} p@lane urow(k) * q[k]  (row I of the forward substitution; p = this lane's a[I])
-template <int M, int I>
+template <int M, int I, int LO = 0>
 TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
   // (row 1 opens the substitution: its column may have just come back from an AGPR -- tools/dpp_hazard_lint.py found
   // exactly that -- so it carries the two wait states itself)
   if constexpr (I == 1)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0)));
+    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0) + LO));
   if constexpr (I == 2)
     asm volatile(DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
-                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0)), "n"(urow<M>(1)));
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0) + LO), "n"(urow<M>(1) + LO));
   if constexpr (I == 3)
     asm volatile(DF3("%0", "%1", "%2", "%5") DF3("%0", "%1", "%3", "%6") DF3("%0", "%1", "%4", "%7")
-                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "n"(urow<M>(0)), "n"(urow<M>(1)), "n"(urow<M>(2)));
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "n"(urow<M>(0) + LO), "n"(urow<M>(1) + LO), "n"(urow<M>(2) + LO));
   if constexpr (I == 4)
     asm volatile(DF3("%0", "%1", "%2", "%6") DF3("%0", "%1", "%3", "%7") DF3("%0", "%1", "%4", "%8")
                      DF3("%0", "%1", "%5", "%9")
-                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "n"(urow<M>(0)), "n"(urow<M>(1)),
-                   "n"(urow<M>(2)), "n"(urow<M>(3)));
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "n"(urow<M>(0) + LO), "n"(urow<M>(1) + LO),
+                   "n"(urow<M>(2) + LO), "n"(urow<M>(3) + LO));
   if constexpr (I == 5)
     asm volatile(DF3("%0", "%1", "%2", "%7") DF3("%0", "%1", "%3", "%8") DF3("%0", "%1", "%4", "%9")
                      DF3("%0", "%1", "%5", "%10") DF3("%0", "%1", "%6", "%11")
-                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "n"(urow<M>(0)),
-                   "n"(urow<M>(1)), "n"(urow<M>(2)), "n"(urow<M>(3)), "n"(urow<M>(4)));
+                 : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "n"(urow<M>(0) + LO),
+                   "n"(urow<M>(1) + LO), "n"(urow<M>(2) + LO), "n"(urow<M>(3) + LO), "n"(urow<M>(4) + LO));
 }
 // t += sum_{k > I} a[k]@lane LN * x[k]  (row I of the back substitution: column I of the factor lives in lane LN = urow(I))
 template <int M, int I, int LN>
@@ -116,13 +116,13 @@ TOLG_DEV void ldl3_update(double (&a)[M], double w) {
 #pragma unroll
   for (int i = J + 1; i < M; i++) a[i] += bcast<LN>(a[i]) * w;
 }
-template <int M, int I>
+template <int M, int I, int LO = 0>
 TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
-  if constexpr (I > 0) y += bcast<urow<M>(0)>(p) * q[0];
-  if constexpr (I > 1) y += bcast<urow<M>(1)>(p) * q[1];
-  if constexpr (I > 2) y += bcast<urow<M>(2)>(p) * q[2];
-  if constexpr (I > 3) y += bcast<urow<M>(3)>(p) * q[3];
-  if constexpr (I > 4) y += bcast<urow<M>(4)>(p) * q[4];
+  if constexpr (I > 0) y += bcast<urow<M>(0) + LO>(p) * q[0];
+  if constexpr (I > 1) y += bcast<urow<M>(1) + LO>(p) * q[1];
+  if constexpr (I > 2) y += bcast<urow<M>(2) + LO>(p) * q[2];
+  if constexpr (I > 3) y += bcast<urow<M>(3) + LO>(p) * q[3];
+  if constexpr (I > 4) y += bcast<urow<M>(4) + LO>(p) * q[4];
 }
 template <int M, int I, int LN>
 TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]) {
@@ -146,30 +146,30 @@ TOLG_DEV void ldl3_bwd_row(double& t, const double (&a)[M], const double (&x)[M]
 // a[J]: it was written by the first multiply-add of the previous pivot's update, M - 1 - J more of them follow, then
 // the v_mul here -- enough except behind the last update (nothing in between) and at pivot 0 (a[0] comes straight from
 // the instruction in front of the statement).
-template <int M, int J>
+template <int M, int J, int LO = 0>
 TOLG_DEV void ldl3_head(const double (&a)[M], double wmJ, double& d, double& pre) {
   if constexpr (J == M - 1) {
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(a[J]), "n"(urow<M>(J)));
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(a[J]), "n"(urow<M>(J) + LO));
     pre = 0.0;
   } else if constexpr (J == 0) {
     asm volatile("v_mul_f64 %1, %2, %3\n\ts_nop 0\n\tv_mov_b64_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J)));
+                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J) + LO));
   } else {
     asm volatile("v_mul_f64 %1, %2, %3\n\tv_mov_b64_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J)));
+                 : "=&v"(d), "=&v"(pre) : "v"(a[J]), "v"(wmJ), "n"(urow<M>(J) + LO));
   }
 }
 #else
-template <int M, int J>
+template <int M, int J, int LO = 0>
 TOLG_DEV void ldl3_head(const double (&a)[M], double wmJ, double& d, double& pre) {
-  d = bcast<urow<M>(J)>(a[J]);
+  d = bcast<urow<M>(J) + LO>(a[J]);
   pre = a[J] * wmJ;
 }
 #endif
-template <int M, int J = 0>
+template <int M, int J = 0, int LO = 0>
 TOLG_DEV void ldl3_factor(double (&a)[M], double (&nri)[M], double (&d)[M], const double (&wm)[M]) {
   double pre;
-  ldl3_head<M, J>(a, wm[J], d[J], pre);
+  ldl3_head<M, J, LO>(a, wm[J], d[J], pre);
   // -1 / d: v_rcp_f64 of -d, two Newton steps on x -> x + x (1 + d x).  A non-positive pivot leaves garbage behind it:
   // the caller discards the factors then.  (One step instead of two, 2.2e-15, was measured and is no faster.)
   double x = __builtin_amdgcn_rcp(-d[J]);
@@ -177,8 +177,8 @@ TOLG_DEV void ldl3_factor(double (&a)[M], double (&nri)[M], double (&d)[M], cons
   x = fma(x, fma(d[J], x, 1.0), x);
   nri[J] = x;
   if constexpr (J + 1 < M) {
-    ldl3_update<M, J, urow<M>(J)>(a, pre * x);  // a[i] -= a[i]@pivot lane * a[J] / d for the columns right of the pivot
-    ldl3_factor<M, J + 1>(a, nri, d, wm);
+    ldl3_update<M, J, urow<M>(J) + LO>(a, pre * x);  // a[i] -= a[i]@pivot lane * a[J] / d for the columns right of the pivot
+    ldl3_factor<M, J + 1, LO>(a, nri, d, wm);
   }
 }
 template <int M>
@@ -189,26 +189,26 @@ TOLG_DEV bool ldl3_all_positive(const double (&d)[M]) {
   return ok;
 }
 // forward substitution in place: y <- L^-1 y, zn_k = -y_k / Dl_k (nri = -1 / Dl, zeroed in the adjoint lane)
-template <int M>
+template <int M, int LO = 0>
 TOLG_DEV void ldl3_forward(const double (&a)[M], const double (&nri)[M], double (&y)[M], double (&zn)[M]) {
   zn[0] = y[0] * nri[0];
-  if constexpr (M > 1) { ldl3_fwd_row<M, 1>(y[1], a[1], zn); zn[1] = y[1] * nri[1]; }
-  if constexpr (M > 2) { ldl3_fwd_row<M, 2>(y[2], a[2], zn); zn[2] = y[2] * nri[2]; }
-  if constexpr (M > 3) { ldl3_fwd_row<M, 3>(y[3], a[3], zn); zn[3] = y[3] * nri[3]; }
-  if constexpr (M > 4) { ldl3_fwd_row<M, 4>(y[4], a[4], zn); zn[4] = y[4] * nri[4]; }
-  if constexpr (M > 5) { ldl3_fwd_row<M, 5>(y[5], a[5], zn); zn[5] = y[5] * nri[5]; }
+  if constexpr (M > 1) { ldl3_fwd_row<M, 1, LO>(y[1], a[1], zn); zn[1] = y[1] * nri[1]; }
+  if constexpr (M > 2) { ldl3_fwd_row<M, 2, LO>(y[2], a[2], zn); zn[2] = y[2] * nri[2]; }
+  if constexpr (M > 3) { ldl3_fwd_row<M, 3, LO>(y[3], a[3], zn); zn[3] = y[3] * nri[3]; }
+  if constexpr (M > 4) { ldl3_fwd_row<M, 4, LO>(y[4], a[4], zn); zn[4] = y[4] * nri[4]; }
+  if constexpr (M > 5) { ldl3_fwd_row<M, 5, LO>(y[5], a[5], zn); zn[5] = y[5] * nri[5]; }
 }
 // back substitution on nx = -x (x = Mt^-1 of the right-hand side), IN PLACE on the forward result y, which nobody
 // needs any more once the rank-m update has read it: y_i += sum_{k>i} (L Dl)[k][i] nx_k, nx_i = -y_i / Dl_i;
 // nx_{M-1} = zn_{M-1}.  No zero-initialised accumulators, no copies.
-template <int M>
+template <int M, int LO = 0>
 TOLG_DEV void ldl3_backward_nx(const double (&a)[M], const double (&nri)[M], double (&y)[M], const double (&zn)[M], double (&nx)[M]) {
   nx[M - 1] = zn[M - 1];
-  if constexpr (M > 1) { ldl3_bwd_row<M, M - 2, urow<M>(M - 2)>(y[M - 2], a, nx); nx[M - 2] = y[M - 2] * nri[M - 2]; }
-  if constexpr (M > 2) { ldl3_bwd_row<M, M - 3, urow<M>(M - 3)>(y[M - 3], a, nx); nx[M - 3] = y[M - 3] * nri[M - 3]; }
-  if constexpr (M > 3) { ldl3_bwd_row<M, M - 4, urow<M>(M - 4)>(y[M - 4], a, nx); nx[M - 4] = y[M - 4] * nri[M - 4]; }
-  if constexpr (M > 4) { ldl3_bwd_row<M, M - 5, urow<M>(M - 5)>(y[M - 5], a, nx); nx[M - 5] = y[M - 5] * nri[M - 5]; }
-  if constexpr (M > 5) { ldl3_bwd_row<M, M - 6, urow<M>(M - 6)>(y[M - 6], a, nx); nx[M - 6] = y[M - 6] * nri[M - 6]; }
+  if constexpr (M > 1) { ldl3_bwd_row<M, M - 2, urow<M>(M - 2) + LO>(y[M - 2], a, nx); nx[M - 2] = y[M - 2] * nri[M - 2]; }
+  if constexpr (M > 2) { ldl3_bwd_row<M, M - 3, urow<M>(M - 3) + LO>(y[M - 3], a, nx); nx[M - 3] = y[M - 3] * nri[M - 3]; }
+  if constexpr (M > 3) { ldl3_bwd_row<M, M - 4, urow<M>(M - 4) + LO>(y[M - 4], a, nx); nx[M - 4] = y[M - 4] * nri[M - 4]; }
+  if constexpr (M > 4) { ldl3_bwd_row<M, M - 5, urow<M>(M - 5) + LO>(y[M - 5], a, nx); nx[M - 5] = y[M - 5] * nri[M - 5]; }
+  if constexpr (M > 5) { ldl3_bwd_row<M, M - 6, urow<M>(M - 6) + LO>(y[M - 6], a, nx); nx[M - 6] = y[M - 6] * nri[M - 6]; }
 }
 
 // LDS slot: up to 5 KB of records (REC_FMAX fields x 32 bytes = 4288), then a 256-byte pad of zeros at the same
@@ -232,6 +232,8 @@ template <int M, bool GRAV, bool AL>
 __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
   // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here
+  // bit 2: fallback behind k_backward4 (tolg_backward4.h): only the groups of four that kernel flagged
+  if ((flags & 4) && !P.k2_redo[blockIdx.x]) return;
   const int ms = flags & 1;
   const bool closed = (flags & 2) != 0;
   const DConsts& C = *(const DConsts*)P.c;

@@ -91,6 +91,7 @@ struct Params {
   double* ls_alpha;    // [Bp]     last alpha tried this iteration
   int* ls_accept;      // [Bp]     accepted alpha index or -1
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
+  int* k2_redo;        // [Bp/4]   groups of four whose sweep k_backward4 handed to k_backward3 (tolg_backward4.h)
   // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
   const double* al_lb;      // [m] or null (= AL off)
   const double* al_ub;      // [m]
@@ -2034,6 +2035,9 @@ TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
 #include "tolg_backward3.h"
+#ifdef TOLG_K2_V4
+#include "tolg_backward4.h"
+#endif
 
 template <int M>
 TOLG_DEV void rl_in_load(const char* slot, int tt, int q, RollIn<M>& R) {
@@ -3088,7 +3092,9 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   double* ls_alpha = c.take<double>(B);
   int* ls_accept = c.take<int>(B);
   int* ls_slot = c.take<int>(B);
+  int* k2_redo = c.take<int>(B / 4 + 1);
   if (P) {
+    P->k2_redo = k2_redo;
     P->slot_x = slot_x; P->slot_u = slot_u; P->Jtrial = Jtrial; P->dtrial = dtrial; P->ecc = ecc;
     P->dweight = dweight; P->ls_alpha = ls_alpha; P->ls_accept = ls_accept; P->ls_slot = ls_slot;
     P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
@@ -3319,6 +3325,19 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
   // of the sweep (tolg_backward3.h).  Dense inertia and the pendulum keep k_backward.
   if (dj && h->prob.kind != TOLG_DYN_PENDULUM3D) {
     const bool al = P.al_lb != nullptr;
+#ifdef TOLG_K2_V4
+    // (experiment, off by default: measured slower -- tolg_backward4.h)  no gravity block, no AL terms, m = 6: the
+    // half-column form, two waves per SIMD, with k_backward3 behind it for the groups it hands back
+    if constexpr (M == 6) {
+      if (h->hc.grav == 0.0 && !al) {
+        hipLaunchKernelGGL((k_backward4<6, false, false>), grid, dim3(128), 0, st, P, it, ms);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_backward3<6, false, false>), grid, blk, 0, st, P, it, ms | 4);
+        LAUNCH_CHECK();
+        return 0;
+      }
+    }
+#endif
     if (h->hc.grav == 0.0) {
       if (al) hipLaunchKernelGGL((k_backward3<M, false, true>), grid, blk, 0, st, P, it, ms);
       else hipLaunchKernelGGL((k_backward3<M, false, false>), grid, blk, 0, st, P, it, ms);
