@@ -38,6 +38,22 @@ def test_rule_on_synthetic_disassembly(between, n_findings):
     assert _dpp_lint.lint(t) == []
 
 
+@pytest.mark.parametrize("between, n_findings", [
+    (["s_mov_b32 s51, m0", "s_mov_b32 m0, s44", "s_nop 0"], 1),   # 3 wait states: what the LDS-DMA statement had
+    (["s_mov_b32 s51, m0", "s_mov_b32 m0, s44", "s_nop 2"], 0),   # 5
+    (["s_nop 3"], 1), (["s_nop 4"], 0),
+])
+def test_sgpr_written_by_valu_then_read_by_vector_memory(between, n_findings):
+    t, a = HEAD + _ins("v_readfirstlane_b32 s64, v130", 0), 8
+    for b in between:
+        t += _ins(b, a); a += 8
+    t += _ins("global_load_lds_dwordx4 v59, s[64:65] offset:1024", a)
+    assert len(_dpp_lint.lint(t)) == n_findings
+    # a scalar-ALU write of the base is no hazard
+    t = HEAD + _ins("s_add_u32 s64, s64, s2", 0) + _ins("global_load_lds_dwordx4 v59, s[64:65]", 8)
+    assert _dpp_lint.lint(t) == []
+
+
 def test_branch_target_in_window_is_reported():
     t = HEAD + _ins("s_cbranch_execz 2 ", 0).replace("//", "// 0 <k+0x10>") + _ins("v_add_f64 v[30:31], v[0:1], v[2:3]", 8) + DPP % 0x10
     assert any("branch target" in f[2] for f in _dpp_lint.lint(t))

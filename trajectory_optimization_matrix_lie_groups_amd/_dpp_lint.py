@@ -12,6 +12,10 @@ compiler actually emitted keeps the distance -- so this lint checks exactly that
     for every DPP instruction: none of the instructions in the two wait states in front of it (program order, s_nop N
     counting N + 1) is a VALU instruction that writes a register of the DPP operand.
 
+Second rule, same reason (the LDS-DMA bursts are inline asm with a scalar base address): a VALU instruction that writes
+an SGPR (v_readfirstlane, v_readlane, a carry-out, a compare) must be five wait states ahead of a vector-memory
+instruction that reads that SGPR.
+
 A branch target inside the window is reported as well (the other predecessor cannot be seen in a linear scan).
 
     python tools/dpp_hazard_lint.py [path/to/libtolg_hip.so]      exit code 1 on a finding
@@ -39,6 +43,21 @@ def disassemble(lib):
 
 
 _REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def _sregs(tok):
+    out = set()
+    for m in _SREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def _is_vmem(op):
+    return op.startswith(("global_", "buffer_", "flat_", "scratch_", "tbuffer_"))
 
 
 def _regs(tok):
@@ -60,6 +79,7 @@ def lint(text):
     findings = []
     kernel = None
     window = []  # (wait_states, opcode, written regs, address, is_label)
+    swindow = []  # the same for VALU writes of SGPRs
     targets = set()
     lines = text.splitlines()
     # branch targets: objdump prints them as <symbol+0xOFF> in the comment of the branch
@@ -71,7 +91,7 @@ def lint(text):
     for ln in lines:
         m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
         if m:
-            kernel, base, window = m.group(2), int(m.group(1), 16), []
+            kernel, base, window, swindow = m.group(2), int(m.group(1), 16), [], []
             continue
         m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
         if not m or kernel is None:
@@ -96,18 +116,37 @@ def lint(text):
                     findings.append((kernel, addr, "%s reads v%s through DPP %d wait state(s) after %s at %x wrote it"
                                      % (op, sorted(w_regs & src0), ws, w_op, w_addr)))
                 ws += w_ws
+        if _is_vmem(op):
+            sread = _sregs(args)
+            ws = 0
+            for w_ws, w_op, w_regs, w_addr, w_label in reversed(swindow):
+                if ws >= 5:
+                    break
+                if w_regs & sread:
+                    findings.append((kernel, addr, "%s reads s%s %d wait state(s) after %s at %x wrote it (VALU write of an SGPR -> "
+                                     "vector memory: 5)" % (op, sorted(w_regs & sread), ws, w_op, w_addr)))
+                ws += w_ws
         # record this instruction
         if op == "s_nop":
             n = int(args.split()[0], 0) if args else 0
             window.append((n + 1, op, set(), addr, False))
+            swindow.append((n + 1, op, set(), addr, False))
         else:
             toks = [t.strip() for t in args.split(",")]
             written = _regs(toks[0]) if toks and _is_valu(op) and not op.startswith("v_cmp") else set()
             if op.startswith("v_accvgpr_write"):
                 written = set()
             window.append((1, op, written, addr, False))
+            # SGPRs a VALU instruction writes: the destination of readlane / readfirstlane, explicit carry / compare outputs
+            swritten = set()
+            if _is_valu(op) and toks:
+                if op.startswith(("v_readfirstlane", "v_readlane")) or "_co_" in op or op.startswith(("v_cmp", "v_div_scale")):
+                    swritten = _sregs(toks[0]) | (_sregs(toks[1]) if ("_co_" in op or op.startswith("v_div_scale")) and len(toks) > 1 else set())
+            swindow.append((1, op, swritten, addr, False))
         if len(window) > 8:
             window = window[-8:]
+        if len(swindow) > 12:
+            swindow = swindow[-12:]
     return findings
 
 

@@ -105,7 +105,7 @@ TOLG_DEV void ldl3_factor_ok(double (&a)[M], double (&nri)[M], const double (&wm
 // two 1-KB LDS-DMA bursts with per-lane source offsets (the second's instruction offset moves both sides by 1024)
 TOLG_DEV void rl_dma16x2v(const void* sbase, unsigned voff0, unsigned voff1, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 2\n\t"
                "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_dst) : "memory");

@@ -2011,11 +2011,14 @@ TOLG_DEV void rl_dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // four consecutive KB with one M0 setting: the instruction offset moves both the global and the LDS address.  base is
-// wave-uniform (SGPR pair), voff the lane's byte offset.  (M0 handling is a quarter of an LDS-DMA's issue time:
+// wave-uniform (SGPR pair), voff the lane's byte offset.  The s_nop 2: base may have been written by a v_readfirstlane
+// directly in front of the statement (uniform_ptr), and a VALU write of an SGPR must be five wait states ahead of the
+// vector-memory instruction that reads it -- the compiler pads its own code, not inline asm
+// (tools/dpp_hazard_lint.py, second rule, found k_rollout_lin's bursts at 3-4).  (M0 handling is a quarter of an LDS-DMA's issue time:
 // tools/lds_dma_microbench.hip)
 TOLG_DEV void rl_dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"
                "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
                "s_mov_b32 m0, %0"
@@ -2023,7 +2026,7 @@ TOLG_DEV void rl_dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
 }
 TOLG_DEV void rl_dma16x3(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"
                "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
                "s_mov_b32 m0, %0"
