@@ -77,7 +77,8 @@ typedef struct {
   double tol_defect;       /* tol_d_norm (MS) */
   double max_reg;          /* max_reg (1e10) */
   int32_t schedule;        /* TOLG_SCHED_* (no reference counterpart: launch structure only) */
-  int32_t reserved;
+  int32_t check_every;     /* tolg_solve_batch: 0 = enqueue all max_iter iterations and never synchronise; k > 0 = issue
+                              them k at a time and stop once every trajectory has finished (tolg_solve_iterate_until) */
 } tolg_options;
 
 typedef struct tolg_handle_s* tolg_handle_t;
@@ -123,11 +124,20 @@ int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_t B, const 
 int tolg_solve_iterate(tolg_handle_t h, int32_t n_iter, void* stream);
 int tolg_solve_end(tolg_handle_t h, double* d_xs_q, double* d_xs_xi, double* d_us, int32_t* d_iters,
                    int32_t* d_status, int32_t* d_converged, void* stream);
+/* Up to n_iter iterations, issued check_every at a time; stops when no trajectory of the batch is iterating any more
+ * -- the early exit of traopt_controller.py:2528-2532 (:1937-1942 single shooting) for the batch as a whole.  Unlike
+ * every other entry point this one waits on the stream: after queueing slice s it waits for the count read back
+ * behind slice s - 1, so the device never idles and a finished batch costs at most one more slice of launches
+ * (finished trajectories are masked, their workgroups exit at once).  check_every = 0, or a solve nothing can end
+ * (multiple shooting with tol_grad = 0 and no line search), is tolg_solve_iterate(n_iter).  *n_issued (may be NULL):
+ * iterations queued. */
+int tolg_solve_iterate_until(tolg_handle_t h, int32_t n_iter, int32_t check_every, int32_t* n_issued, void* stream);
 /* Number of trajectories of the solve in flight that are still being iterated (not converged, not stopped by
- * a status), written to d_count[0] on `stream`.  The library never synchronises, so tolg_solve_batch always
- * enqueues max_iter iterations (finished trajectories are masked, finished workgroups exit at once); a caller
+ * a status), written to d_count[0] on `stream`.  Apart from tolg_solve_iterate_until the library never synchronises: with
+ * check_every = 0 tolg_solve_batch enqueues max_iter iterations (finished trajectories are masked, finished workgroups
+ * exit at once); a caller
  * that wants the early exit of traopt_controller.py:2528-2532 issues the iterations in slices and reads this
- * count between them (BatchedTrackingILQR.fit_batch does). */
+ * count between them, or calls tolg_solve_iterate_until, which pipelines exactly that. */
 int tolg_solve_active_count(tolg_handle_t h, int32_t* d_count, void* stream);
 /* Same export without ending the solve: what the per-iteration on_iteration callback of
  * traoptlibrary/traopt_controller.py:2621-2626 needs (current xs, us) when a caller wants it. */

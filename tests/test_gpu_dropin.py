@@ -85,3 +85,11 @@ def test_solve_peek_and_active_count_between_slices():
     # the sliced fit with the early exit stops issuing launches but returns the same result
     early = s.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=60, tol_grad_norm=1e-7, check_every=4)
     assert torch.equal(early.us, ref_us) and torch.equal(early.iters, ref_iters)
+    # ... one slice past the first count of zero at most (tolg_solve_iterate_until looks one slice behind)
+    done_at = int(ref_iters.max())
+    assert done_at < 52 and s.iterations_issued <= (done_at + 3) // 4 * 4 + 8 and s.iterations_issued % 4 == 0
+    # a solve that nothing can end is one slice, and the one-call entry point takes the same option
+    free = s.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=12, tol_grad_norm=0.0, tol_d_norm=0.0, check_every=4)
+    assert s.iterations_issued == 12 and int(free.iters.min()) == 12
+    one = s.solve_batch_one_call(x0_q, x0_xi, us0, mode="ms", n_iterations=60, tol_grad_norm=1e-7, check_every=4)
+    assert torch.equal(one.us, ref_us) and torch.equal(one.iters, ref_iters)

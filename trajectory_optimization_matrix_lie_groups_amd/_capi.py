@@ -20,12 +20,12 @@ class Problem(C.Structure):
 class Options(C.Structure):
     _fields_ = [("mode", C.c_int32), ("max_iter", C.c_int32), ("line_search", C.c_int32),
                 ("rollout_linear", C.c_int32), ("tol_grad", C.c_double), ("tol_defect", C.c_double),
-                ("max_reg", C.c_double), ("schedule", C.c_int32), ("reserved", C.c_int32)]
+                ("max_reg", C.c_double), ("schedule", C.c_int32), ("check_every", C.c_int32)]
 
 
 _lib = None
 SYMBOLS = ["tolg_workspace_bytes", "tolg_create", "tolg_destroy", "tolg_solve_batch", "tolg_solve_begin",
-           "tolg_solve_iterate", "tolg_solve_end", "tolg_solve_peek", "tolg_solve_active_count", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
+           "tolg_solve_iterate", "tolg_solve_iterate_until", "tolg_solve_end", "tolg_solve_peek", "tolg_solve_active_count", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
            "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version", "tolg_selftest_series"]
 
 
@@ -54,6 +54,8 @@ def load():
     lib.tolg_solve_begin.argtypes = [vp, C.POINTER(Options), C.c_int32] + [dp] * 8 + [vp]
     lib.tolg_solve_iterate.restype = C.c_int
     lib.tolg_solve_iterate.argtypes = [vp, C.c_int32, vp]
+    lib.tolg_solve_iterate_until.restype = C.c_int
+    lib.tolg_solve_iterate_until.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), vp]
     lib.tolg_solve_end.restype = C.c_int
     lib.tolg_solve_end.argtypes = [vp, dp, dp, dp, ip, ip, ip, vp]
     lib.tolg_solve_peek.restype = C.c_int

@@ -3025,6 +3025,9 @@ struct tolg_handle_s {
   int lds_per_block;  // hipDeviceAttributeMaxSharedMemoryPerBlock of the current device (160 KB on MI355X)
   int rec_closed = 0; // the knot records were last written by the fused rollout (no defect field, see k_backward)
   const double *al_lb, *al_ub, *al_lambda, *al_imu;  // augmented-Lagrangian terms (null = off)
+  // early exit of a sliced solve (tolg_solve_iterate_until): two device counters, their pinned host copies, two events
+  int *d_cnt = nullptr, *h_cnt = nullptr;
+  hipEvent_t cnt_ev[2] = {nullptr, nullptr};
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -3233,6 +3236,11 @@ extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, cons
 }
 
 extern "C" void tolg_destroy(tolg_handle_t h) {
+  if (h) {
+    if (h->d_cnt) (void)hipFree(h->d_cnt);
+    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    for (int k = 0; k < 2; k++) if (h->cnt_ev[k]) (void)hipEventDestroy(h->cnt_ev[k]);
+  }
   if (!h) return;
   for (auto e : h->ev) (void)hipEventDestroy(e);
   delete h;
@@ -3565,6 +3573,50 @@ extern "C" int tolg_solve_active_count(tolg_handle_t h, int32_t* d_count, void* 
   return 0;
 }
 
+extern "C" int tolg_solve_iterate_until(tolg_handle_t h, int32_t n_iter, int32_t check_every, int32_t* n_issued, void* stream) {
+  if (!h || !h->running || n_iter < 0 || check_every < 0) return TOLG_E_ARG;
+  if (h->run_it + n_iter > h->run_opt.max_iter) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const tolg_options& o = h->run_opt;
+  // nothing can end a solve whose tolerances are zero (accept-always MS): one slice, no read-back
+  const bool can_stop = check_every > 0 && (o.tol_grad > 0 || o.line_search || o.mode != TOLG_MODE_MS);
+  int rc, done = 0;
+  if (!can_stop) {
+    if ((rc = tolg_solve_iterate(h, n_iter, stream))) return rc;
+    if (n_issued) *n_issued = n_iter;
+    return 0;
+  }
+  if (!h->d_cnt) {
+    if (hipMalloc((void**)&h->d_cnt, 2 * sizeof(int)) != hipSuccess) return TOLG_E_LAUNCH;
+    if (hipHostMalloc((void**)&h->h_cnt, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return TOLG_E_LAUNCH;
+    for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&h->cnt_ev[k], hipEventDisableTiming) != hipSuccess) return TOLG_E_LAUNCH;
+  }
+  // Slices of check_every iterations; behind each, the count of trajectories still iterating goes to pinned host
+  // memory.  The host looks at the count of the slice BEFORE the one it has just queued, so the device always has a
+  // slice in its queue while the host waits: a converged batch costs at most one slice of launches whose workgroups
+  // exit at once (traopt_controller.py:2528-2532 is the per-trajectory exit this adds up to).
+  int slice = 0, pending = -1;
+  while (done < n_iter) {
+    const int step = (n_iter - done < check_every) ? n_iter - done : check_every;
+    if ((rc = tolg_solve_iterate(h, step, stream))) return rc;
+    done += step;
+    const int k = slice & 1;
+    if (hipMemsetAsync(h->d_cnt + k, 0, sizeof(int), st) != hipSuccess) return TOLG_E_LAUNCH;
+    hipLaunchKernelGGL(k_active_count, dim3((h->run.B + 255) / 256), dim3(256), 0, st, h->run, h->d_cnt + k);
+    LAUNCH_CHECK();
+    if (hipMemcpyAsync(h->h_cnt + k, h->d_cnt + k, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return TOLG_E_LAUNCH;
+    if (hipEventRecord(h->cnt_ev[k], st) != hipSuccess) return TOLG_E_LAUNCH;
+    if (pending >= 0) {
+      if (hipEventSynchronize(h->cnt_ev[pending]) != hipSuccess) return TOLG_E_LAUNCH;
+      if (h->h_cnt[pending] == 0) break;
+    }
+    pending = k;
+    slice++;
+  }
+  if (n_issued) *n_issued = done;
+  return 0;
+}
+
 extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_t B, const double* d_x0_q,
                                 const double* d_x0_xi, const double* d_us_init, double* d_xs_q, double* d_xs_xi,
                                 double* d_us, double* d_J_hist, double* d_grad_hist, double* d_defect_hist,
@@ -3573,7 +3625,7 @@ extern "C" int tolg_solve_batch(tolg_handle_t h, const tolg_options* opt, int32_
   int rc = tolg_solve_begin(h, opt, B, d_x0_q, d_x0_xi, d_us_init, d_J_hist, d_grad_hist, d_defect_hist, d_alpha_hist,
                             d_mu_hist, stream);
   if (rc) return rc;
-  if ((rc = tolg_solve_iterate(h, opt->max_iter, stream))) return rc;
+  if ((rc = tolg_solve_iterate_until(h, opt->max_iter, opt->check_every, nullptr, stream))) return rc;
   return tolg_solve_end(h, d_xs_q, d_xs_xi, d_us, d_iters, d_status, d_converged, stream);
 }
 

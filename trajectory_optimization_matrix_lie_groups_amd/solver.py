@@ -189,6 +189,15 @@ class BatchedTrackingILQR:
             rc = self.lib.tolg_solve_iterate(self._h, int(n_iter), self._stream())
         _capi.check(rc, "tolg_solve_iterate")
 
+    def solve_iterate_until(self, n_iter, check_every) -> int:
+        """Up to n_iter iterations in slices of check_every, stopping once no trajectory is iterating any more
+        (tolg_solve_iterate_until: the read-back of one slice overlaps the next).  Returns the iterations queued."""
+        n = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_iterate_until(self._h, int(n_iter), int(check_every), C.byref(n), self._stream())
+        _capi.check(rc, "tolg_solve_iterate_until")
+        return int(n.value)
+
     def active_count(self) -> int:
         """Trajectories of the solve in flight that are still being iterated (one small kernel + a host read)."""
         if getattr(self, "_active_buf", None) is None:
@@ -220,25 +229,40 @@ class BatchedTrackingILQR:
                   histories=True, out: Optional[FitResult] = None, schedule="auto", check_every=16) -> FitResult:
         """B independent fits (the reference's joblib fan-out, visualization/perturb_all_compute.py:240).
         Inputs may be numpy arrays or tensors already on the device; outputs are device tensors.
-        The iterations are issued in slices of `check_every`; between slices the number of trajectories still
-        iterating is read back and the loop stops when it reaches zero (the early exit of
-        traopt_controller.py:2528-2532 for the whole batch).  check_every=0, or tolerances of zero, issue all
-        n_iterations without a host read."""
+        The iterations are issued in slices of `check_every`; behind each slice the number of trajectories still
+        iterating is read back (overlapped with the next slice) and the loop stops when it reaches zero (the early
+        exit of traopt_controller.py:2528-2532 for the whole batch).  check_every=0, or tolerances of zero, issue
+        all n_iterations without a host read.  `iterations_issued` keeps how many were queued."""
         self.solve_begin(x0_q, x0_xi, us_init, mode, n_iterations, tol_grad_norm, tol_d_norm, line_search, rollout,
                          max_reg, histories, out, schedule)
-        n = int(n_iterations)
-        can_stop = check_every and (tol_grad_norm > 0 or line_search or mode == "ss")
-        if not can_stop:
-            self.solve_iterate(n)
-        else:
-            done = 0
-            while done < n:
-                step = min(int(check_every), n - done)
-                self.solve_iterate(step)
-                done += step
-                if done < n and self.active_count() == 0:
-                    break
+        self.iterations_issued = self.solve_iterate_until(int(n_iterations), int(check_every or 0))
         return self.solve_end()
+
+    def solve_batch_one_call(self, x0_q, x0_xi, us_init=None, mode="ms", n_iterations=100, tol_grad_norm=1e-6,
+                             tol_d_norm=1e-6, line_search=False, rollout="nonlinear", max_reg=1e10, schedule="auto",
+                             check_every=0) -> FitResult:
+        """The same fit through the single entry point tolg_solve_batch (what a C / C++ caller binds): begin,
+        iterations (tolg_options.check_every: 0 = all of them, never synchronising), end in one call."""
+        x0_q = self._dev(x0_q, (-1, 16))
+        B = x0_q.shape[0]
+        x0_xi = self._dev(x0_xi, (B, 6))
+        if us_init is None:
+            us_init = torch.zeros((B, self.N, self.m), dtype=torch.float64, device=self.device)
+        us_init = self._dev(us_init, (B, self.N, self.m))
+        K = int(n_iterations)
+        out = self._alloc_result(B, K, True)
+        o = _capi.Options(_capi.MODE_MS if mode == "ms" else _capi.MODE_SS, K, int(bool(line_search)),
+                          int(rollout == "linear"), float(tol_grad_norm), float(tol_d_norm),
+                          float(max_reg if max_reg else 0.0),
+                          {"auto": _capi.SCHED_AUTO, "split": _capi.SCHED_SPLIT}[schedule], int(check_every))
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_solve_batch(self._h, C.byref(o), B, _ptr(x0_q), _ptr(x0_xi), _ptr(us_init), _ptr(out.xs_q),
+                                           _ptr(out.xs_xi), _ptr(out.us), _ptr(out.J_hist), _ptr(out.grad_hist),
+                                           _ptr(out.defect_hist), _ptr(out.alpha_hist), _ptr(out.mu_hist), _ptr(out.iters),
+                                           _ptr(out.status), _ptr(out.converged), self._stream())
+        _capi.check(rc, "tolg_solve_batch")
+        torch.cuda.current_stream(self.device).synchronize()  # the inputs above must outlive the queued work
+        return out
 
     # ------------------------------------------------------------------------------------------
     def set_al(self, lb=None, ub=None, lam=None, imu=None):
