@@ -433,6 +433,9 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + NKB) : "memory");
 #endif
+    // (One VALU instruction stands in front of most of these reads: the lane's address comes back from an AGPR.  With
+    // absolute addresses and the slot as an instruction immediate the v_add of the slot-relative form went, the AGPR
+    // read stayed: no gain, not kept.)
     // (Fencing these reads into use order -- the six that open the Z product first, [l_xx | l_x] and l_u behind its first
     // block -- was measured: +0.02 ms.  The compiler's order stays.)
     double A[12], Qh[12], lu[M], luu_i = 0.0;
@@ -482,14 +485,16 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     STAMP(1)
 #endif
     gk_run -= gStride;
-#if TOLG_K3_X != 2
+#if TOLG_K3_X == 5 || TOLG_K3_X == 6  // gains only from the first sweep of a solve (later sweeps: no stores)
+    if (i < N - 1 && it <= 0) store_gains(gk_run);
+#elif TOLG_K3_X != 2
     if (i < N - 1) store_gains(gk_run);
 #endif
 #ifdef TOLG_STAMPS2
     STAMP(2)
 #endif
     rec_run -= recStrideB;
-#if TOLG_K3_X != 3
+#if TOLG_K3_X != 3 && TOLG_K3_X != 6
     if (i >= 2) dma_from(rec_run, SLOT);
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // factor of two knots (~1.2 measured, 4 at worst), which leaves it at rounding level.
 #ifdef TOLG_K3_SYM1
     constexpr bool SYM = true;
-#elif TOLG_K3_X == 4
+#elif TOLG_K3_X == 4 || TOLG_K3_X == 6
     constexpr bool SYM = false;
 #else
     constexpr bool SYM = SLOT == 0;
