@@ -1652,13 +1652,34 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
   }
   double rte[3] = {0, 0, 0};  // the field exists for gravity models only
   if (C.grav != 0.0) { rte[0] = P.REC[RIDX(i, REC_LU + M, b)]; rte[1] = P.REC[RIDX(i, REC_LU + M + 1, b)]; rte[2] = P.REC[RIDX(i, REC_LU + M + 2, b)]; }
-  double a22[36];
-  a22_get(P, C, i, b, a22);
+  // velocity block times e[6:12].  Where the record holds it (dense inertia, pendulum) it is read entry by entry;
+  // where it does not (diagonal inertia: every reference script) it is applied WITHOUT being formed -- with
+  // J = blkdiag(Ib, Jv), (coadjoint([v, w]) J + G) [a; c] = [(Ib w) x a - v x (Ib a) + m v x c - w x (Jv c);
+  // m v x a - v x (Jv c)] (a22_build), six cross products instead of a 36-entry matrix in registers: the linear
+  // rollouts of the merit search (k_expected_change, k_rollout_eval<LINEAR>) spilled 160-470 registers to scratch with
+  // the matrix form, 4.2 ms per k_expected_change call at 4096 x 200.
+  double he[6] = {0, 0, 0, 0, 0, 0};
+  if (P.fA22 < 0) {
+    const V3 w = v3(P.REC[RIDX(i, REC_XI, b)], P.REC[RIDX(i, REC_XI + 2, b)], P.REC[RIDX(i, REC_XI + 4, b)]);
+    const V3 v = v3(P.REC[RIDX(i, REC_XI + 1, b)], P.REC[RIDX(i, REC_XI + 3, b)], P.REC[RIDX(i, REC_XI + 5, b)]);
+    const V3 a = v3(e[6], e[7], e[8]), c = v3(e[9], e[10], e[11]);
+    V3 top, bot = v3(0, 0, 0);
+    if (so3_family(C.kind)) {
+      top = cross(mv33(C.Ib, w), a) - cross(w, mv33(C.Ib, a));
+    } else {
+      top = (cross(mv33(C.Ib, w), a) - cross(v, mv33(C.Ib, a))) + (C.mass * cross(v, c) - cross(w, mv33(C.Jv, c)));
+      bot = C.mass * cross(v, a) - cross(v, mv33(C.Jv, c));
+    }
+    const V3 ht = mv33(C.Ibinv, top), hb = mv33(C.Jvinv, bot);
+    he[0] = C.dt * ht.x; he[1] = C.dt * ht.y; he[2] = C.dt * ht.z; he[3] = C.dt * hb.x; he[4] = C.dt * hb.y; he[5] = C.dt * hb.z;
+  }
 #pragma unroll
   for (int r = 0; r < 6; r++) {
-    double sacc = e[6 + r];
+    double sacc = e[6 + r] + he[r];
+    if (P.fA22 >= 0) {
 #pragma unroll
-    for (int c = 0; c < 6; c++) sacc += (a22[6 * c + r] - (r == c ? 1.0 : 0.0)) * e[6 + c];
+      for (int c = 0; c < 6; c++) sacc += (P.REC[RIDX(i, P.fA22 + 6 * c + r, b)] - (r == c ? 1.0 : 0.0)) * e[6 + c];
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       double l = rte[0] * C.Llin[0][6 * r + c] + rte[1] * C.Llin[1][6 * r + c] + rte[2] * C.Llin[2][6 * r + c];
