@@ -3049,6 +3049,9 @@ struct tolg_handle_s {
   // early exit of a sliced solve (tolg_solve_iterate_until): two device counters, their pinned host copies, two events
   int *d_cnt = nullptr, *h_cnt = nullptr;
   hipEvent_t cnt_ev[2] = {nullptr, nullptr};
+  // merit search: the linear alpha = 1 rollout (k_expected_change) runs on a side stream beside the first line-search stage
+  hipStream_t side = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
   // timing
   bool timing;
   std::vector<hipEvent_t> ev;  // pairs
@@ -3261,6 +3264,8 @@ extern "C" void tolg_destroy(tolg_handle_t h) {
     if (h->d_cnt) (void)hipFree(h->d_cnt);
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     for (int k = 0; k < 2; k++) if (h->cnt_ev[k]) (void)hipEventDestroy(h->cnt_ev[k]);
+    for (int k = 0; k < 2; k++) if (h->side_ev[k]) (void)hipEventDestroy(h->side_ev[k]);
+    if (h->side) (void)hipStreamDestroy(h->side);
   }
   if (!h) return;
   for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -3414,7 +3419,8 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
   return 0;
 }
 template <int M, bool MS>
-static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a0, int n, int linear) {
+static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a0, int n, int linear,
+                        hipEvent_t before_select = nullptr) {
   // alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.  A one-alpha stage writes its candidate in
   // place (no slot, no copy); a trajectory that has accepted leaves the later stages at once.
   const int direct = n == 1;
@@ -3437,6 +3443,7 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a
     }
     LAUNCH_CHECK();
   }
+  if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
   hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n);
   LAUNCH_CHECK();
   if (!direct) {
@@ -3470,16 +3477,24 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
     } else {
       hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
       LAUNCH_CHECK();
+      // the defect weight's linear rollout on a side stream: the first stage's rollout does not need it, its select does
+      // (both are 256-wave latency chains; side by side they take the longer one's time, not the sum)
+      if (!h->side) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return TOLG_E_LAUNCH;
+        for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&h->side_ev[k], hipEventDisableTiming) != hipSuccess) return TOLG_E_LAUNCH;
+      }
+      if (hipEventRecord(h->side_ev[0], st) != hipSuccess || hipStreamWaitEvent(h->side, h->side_ev[0], 0) != hipSuccess) return TOLG_E_LAUNCH;
       if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
-        hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+        hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       else
-        hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+        hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       LAUNCH_CHECK();
+      if (hipEventRecord(h->side_ev[1], h->side) != hipSuccess) return TOLG_E_LAUNCH;
       // staged: the first try alone (the common accept: one quad rollout, written in place), then 4 + 8 (+ 7) alphas
       // of the trajectories still undecided -- iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20
       // (:2472).  Measured: the merit search of this workload rarely accepts the first alpha, and one stage of 19
       // took 5.2 ms against 3 x 0.7.
-      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
       if (!so3_family(h->prob.kind))
