@@ -23,3 +23,5 @@ tot = st[:7].sum()
 for n, v in zip(names, st):
     print("%-52s %8.0f cycles/knot  %5.1f %%" % (n, v / N, 100 * v / tot))
 print("total per knot %.0f (s_memtime ticks)" % (tot / N))
+rt = r.mu_hist[29, :2].cpu().numpy()
+print("the sweep of this wave: %.1f us by s_memrealtime (100 MHz), %.0f s_memtime ticks -> %.2f GHz" % (rt[0] / 100.0, rt[1], rt[1] / (rt[0] / 100.0) / 1e3))

@@ -415,6 +415,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   };
 #ifdef TOLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_ct0 = st_t;
 #endif
 
   // ---- one knot.  SLOT (compile time): the LDS slot that holds knot i; the loop below is unrolled by two.
@@ -716,7 +717,11 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   store_gains(P.GK);
 #ifdef TOLG_STAMPS
   STAMP(7)
-  if (blockIdx.x == 7 && lane == 0 && P.mu_hist) { for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st_acc[k]; }
+  if (blockIdx.x == 7 && lane == 0 && P.mu_hist) {
+    for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st_acc[k];
+    P.mu_hist[(size_t)29 * P.max_iter + 0] = (double)(__builtin_amdgcn_s_memrealtime() - st_rt0);  // 100 MHz ticks
+    P.mu_hist[(size_t)29 * P.max_iter + 1] = (double)(__builtin_amdgcn_s_memtime() - st_ct0);
+  }
 #endif
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942)
   double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;

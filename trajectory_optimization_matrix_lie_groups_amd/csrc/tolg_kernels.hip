@@ -2059,6 +2059,9 @@ TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
 #include "tolg_backward3.h"
+#ifdef TOLG_K2_V5
+#include "tolg_backward5.h"
+#endif
 #ifdef TOLG_K2_V4
 #include "tolg_backward4.h"
 #endif
@@ -3362,6 +3365,19 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
   // of the sweep (tolg_backward3.h).  Dense inertia and the pendulum keep k_backward.
   if (dj && h->prob.kind != TOLG_DYN_PENDULUM3D) {
     const bool al = P.al_lb != nullptr;
+#ifdef TOLG_K2_V5
+    // (experiment, off by default: measured slower -- tolg_backward5.h)  no gravity block, no AL terms, m = 6: the
+    // wave-pair form, with k_backward3 behind it for the groups it hands back
+    if constexpr (M == 6) {
+      if (h->hc.grav == 0.0 && !al && P.N >= 8) {
+        hipLaunchKernelGGL((k_backward5<6>), grid, dim3(128), 0, st, P, it, ms);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_backward3<6, false, false>), grid, blk, 0, st, P, it, ms | 4);
+        LAUNCH_CHECK();
+        return 0;
+      }
+    }
+#endif
 #ifdef TOLG_K2_V4
     // (experiment, off by default: measured slower -- tolg_backward4.h)  no gravity block, no AL terms, m = 6: the
     // half-column form, two waves per SIMD, with k_backward3 behind it for the groups it hands back
