@@ -6,13 +6,12 @@
 // profiles/r03_k5_*).  It does what it was built for -- no duplicated instructions (560 per knot and group against
 // k_backward3's 571), wave B's critical path 3 470 cycles per knot against 4 180, both measured at the same 1.97 GHz
 // in one run (tools/k5_stamps.py, tools/k2_stamps.py) -- and the LAUNCH is slower: 0.455 ms against 0.343 under
-// rocprofv3, 0.40-0.42 against 0.355 in the bench.  The two waves of a pair are unequal (A: 180 vector instructions per
-// knot, B: 350 on the critical path) and which two waves share a SIMD is the dispatcher's choice: a SIMD that gets two
-// B waves runs 700 instructions per knot, one that gets two A waves idles, and the launch ends with the slowest
-// workgroup.  Four ways of assigning the roles by workgroup index (TOLG_K5_SWAP) all land on the same time.  Equal
-// roles would need the waves to trade their halves of V every knot (another LDS round trip on the critical path), and
-// even perfectly balanced the pair is paced by B's path: 3 470 cycles against 4 180 is 17 %, of which the second launch
-// for the handed-back groups and the exchanges still to hide would take most.
+// rocprofv3, 0.40-0.42 against 0.355 in the bench (two-wave workgroups, roles by wave index).  The two waves of a pair
+// are unequal (A: 180 vector instructions per knot, B: 350 on the critical path), so which waves share a SIMD matters;
+// the form below makes that exact -- four-wave workgroups, roles from the SIMD a wave finds itself on, one A and one B
+// per SIMD (tools/hwid_probe.hip) -- and is slower still (0.437 ms): two groups now share every barrier.  The pair is
+// paced by B's path plus what the exchanges and barriers leave exposed, and a second launch redoes the handed-back
+// groups; 17 % fewer cycles on B's path do not pay for that.
 //
 // Why.  k_backward3 is one wave per SIMD issuing 571 vector instructions per knot at 5.8 cycles each; two resident waves
 // issue at 4.4-4.5 per SIMD (profiles/r03_valu_issue_microbench.txt).  The half-column form of tolg_backward4.h got two
@@ -112,51 +111,62 @@ enum { S5_DATA = 3072, S5_ZP = S5_DATA, S5_ZBYTES = 256, S5_KB = S5_ZP + S5_ZBYT
        S5_FLAG = S5_RT + S5_RTBYTES, S5_LDS = S5_FLAG + 16 };
 static_assert(S5_SLOT % 16 == 0 && S5_KB % 16 == 0 && S5_VB % 16 == 0, "16-byte aligned regions");
 
-#ifndef TOLG_K5_SWAP
-#define TOLG_K5_SWAP 1  // which wave of a workgroup takes which role alternates with the workgroup index (SIMD balance)
-#endif
-
+// Which two waves share a SIMD decides everything here (A issues ~180 vector instructions per knot, B ~350 on the critical
+// path): a SIMD must get one of each.  tools/hwid_probe.hip (profiles/r03_hwid_probe.txt): the four waves of a 256-thread
+// workgroup always land on the four SIMDs of one CU (cyclic order 0 -> 2 -> 1 -> 3 from a varying start), and with 70 KB
+// of LDS per workgroup a CU hosts exactly workgroups b and b + 256 of a 512-workgroup grid.  So a workgroup carries TWO
+// groups of four trajectories, a wave reads the SIMD it runs on from HW_ID, and the role follows from that: SIMDs 0, 1
+// take the A waves and 2, 3 the B waves in workgroups with (blockIdx / 256) even, the other way round in the odd ones;
+// the waves on SIMDs s and s + 2 form a pair.  The claims are checked through LDS before anything else: a workgroup
+// whose waves do not form two pairs hands both groups to k_backward3.
 template <int M>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_backward5(Params P, int it, int flags) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_backward5(Params P, int it, int flags) {
   static_assert(M == 6, "SE3 / rigid body / SO3");
   const int ms = flags & 1;
   const bool closed = (flags & 2) != 0;
   const DConsts& C = *(const DConsts*)P.c;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#if TOLG_K5_SWAP == 1
-  const bool isB = ((wv ^ (int)(blockIdx.x >> 1)) & 1) != 0;
-#elif TOLG_K5_SWAP == 2
-  const bool isB = ((wv ^ (int)blockIdx.x) & 1) != 0;
-#elif TOLG_K5_SWAP == 3
-  const bool isB = ((wv ^ (int)(blockIdx.x >> 8)) & 1) != 0;
-#else
-  const bool isB = wv != 0;
-#endif
+  const int lane = threadIdx.x & 63;
+  const unsigned simd = (__builtin_amdgcn_s_getreg(4 | (31 << 11)) >> 4) & 3u;  // HW_REG_HW_ID: SIMD_ID
+  const int par = (int)(blockIdx.x >> 8) & 1;
+  const bool isB = ((int)(simd >> 1) ^ par) != 0;
+  const int gi = (int)(simd & 1u);              // which of the workgroup's two groups
+  const int H = isB ? 1 : 0;
+  __shared__ __attribute__((aligned(16))) char lds_all[2 * S5_LDS];
+  __shared__ int claim[4];
+  if (threadIdx.x < 4) claim[threadIdx.x] = 0;
+  w5_barrier();
+  if (lane == 0) atomicAdd(&claim[2 * gi + H], 1);
+  w5_barrier();
+  const bool paired = claim[0] == 1 && claim[1] == 1 && claim[2] == 1 && claim[3] == 1;
+  char* lds = lds_all + gi * S5_LDS;
+  const int grp = 2 * (int)blockIdx.x + gi;     // group of four trajectories (record / gain group index)
+  const int ngrp = P.Bp / 4;
+  if (grp >= ngrp) return;                      // (odd number of groups: the last workgroup carries one)
   const int g = lane >> 4, j = lane & 15;
-  const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
+  const int b = grp * 4 + g;
   const bool act = P.active[b] != 0;
   const int N = P.N;
-  __shared__ __attribute__((aligned(16))) char lds[S5_LDS];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   double mu = P.mu[b], delta = P.delta[b];
+  const int tl = lane + 64 * H;                 // thread index inside the pair
   // ---- LDS constants (both waves take a share; the first barrier below covers them)
-  for (int k = threadIdx.x; k < S5_NSLOT * (S5_SLOT - S5_DATA) / 8; k += 128) {
+  for (int k = tl; k < S5_NSLOT * (S5_SLOT - S5_DATA) / 8; k += 128) {
     const int s = k / ((S5_SLOT - S5_DATA) / 8), o = S5_DATA + 8 * (k % ((S5_SLOT - S5_DATA) / 8));
     double v = 0.0;
     if (o >= S5_KB && o < S5_VB) { const int e = (o - S5_KB) / 8, c6 = e / 6, r6 = e % 6; v = 2.0 * C.W2[6 * r6 + c6]; }  // [c6][r6]
     if (o >= S5_VB) { const int e = (o - S5_VB) / 8, c6 = (e / 6) % 6, r6 = e % 6; v = (c6 == r6) ? 1.0 : 0.0; }          // [g][c6][r6]
     *reinterpret_cast<double*>(lds + s * S5_SLOT + o) = v;
   }
-  if (threadIdx.x < 64) reinterpret_cast<double*>(lds + S5_TZERO)[threadIdx.x] = 0.0;
-  if (threadIdx.x < 8) {
-    const int u = threadIdx.x < M ? threadIdx.x : 0;
-    const double bq = (threadIdx.x < M) ? fu_entry<M>(*P.c, urow<M>(u) - 6, u) : 1.0;  // generic pointer: note at DConsts
-    reinterpret_cast<double*>(lds + S5_BU)[threadIdx.x] = bq;
-    reinterpret_cast<double*>(lds + S5_IBU)[threadIdx.x] = 1.0 / bq;
+  if (tl < 64) reinterpret_cast<double*>(lds + S5_TZERO)[tl] = 0.0;
+  if (tl < 8) {
+    const int u = tl < M ? tl : 0;
+    const double bq = (tl < M) ? fu_entry<M>(*P.c, urow<M>(u) - 6, u) : 1.0;  // generic pointer: note at DConsts
+    reinterpret_cast<double*>(lds + S5_BU)[tl] = bq;
+    reinterpret_cast<double*>(lds + S5_IBU)[tl] = 1.0 / bq;
   }
-  if (threadIdx.x == 0) *reinterpret_cast<int*>(lds + S5_FLAG) = 0;
-  if (threadIdx.x < 16) {  // column of 2 D^-1 R D^-1 that the lane of column jj holds (zero where it holds none)
-    const int jj = threadIdx.x;
+  if (tl == 0) *reinterpret_cast<int*>(lds + S5_FLAG) = 0;
+  if (tl < 16) {  // column of 2 D^-1 R D^-1 that the lane of column jj holds (zero where it holds none)
+    const int jj = tl;
     int mc = -1;
 #pragma unroll
     for (int u = 0; u < M; u++) if (jj == urow<M>(u)) mc = u;
@@ -176,7 +186,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool vcol = j >= 6 && j < 12;
   const unsigned lg = (unsigned)g * 16u;
   const unsigned ZP = (unsigned)S5_ZP;
-  const int H = isB ? 1 : 0;
   auto fx_off = [&](int k) -> unsigned {  // field of [F_x | d][k][j], or where it is structurally 0 / in the image
     if (j == 12) return hasD ? lg + FOFF(REC_D + k) : ZP;
     if (j > 12) return ZP;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   auto of_flag = [&]() -> bool { return *reinterpret_cast<const int*>(lds + S5_FLAG) != 0; };  // (read behind a barrier statement, which is a compiler memory fence)
-  bool stopped = __any(act && mu != 0.0);  // regularised knots ahead (the first sweep of a solve): k_backward3
+  bool stopped = __any(act && mu != 0.0) || !paired;  // regularised knots ahead (the first sweep of a solve): k_backward3
   // (the same four trajectories in both waves: the same verdict, so the barriers below stay matched)
   const bool run = __any(act) && !stopped && N >= S5_NSLOT;
   if (N < S5_NSLOT) stopped = true;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       *reinterpret_cast<double*>(sn + oWA + 24) = eA1; *reinterpret_cast<double*>(sn + oWB + 24) = eB1;
     };
     auto dma_knot = [&](int i) {
-      const char* src = reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes;
+      const char* src = reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)grp * blockBytes;
       const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(i & 3) * S5_SLOT));
       rl_dma16x3(uniform_ptr(src), (unsigned)lane * 16u, dst);
     };
@@ -549,14 +558,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (!stopped) store_gains(P.GK);
 #ifdef TOLG_STAMPS5
-    if (blockIdx.x == 7 && lane == 0 && P.mu_hist) {
+    if (grp == 7 && lane == 0 && P.mu_hist) {
       for (int k = 0; k < 8; k++) P.mu_hist[(size_t)28 * P.max_iter + k] = (double)st5[k];
       P.mu_hist[(size_t)29 * P.max_iter + 0] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
       P.mu_hist[(size_t)29 * P.max_iter + 1] = (double)(__builtin_amdgcn_s_memtime() - ct0);
     }
 #endif
   }
-  if (isB && threadIdx.x % 64 == 0) P.k2_redo[blockIdx.x] = stopped ? 1 : 0;
+  if (isB && lane == 0) P.k2_redo[grp] = stopped ? 1 : 0;
   if (stopped || !isB) return;  // a stopped group's sweep is k_backward3's: nothing of the epilogue may have happened
   // ---- epilogue: gradient norm, convergence test (traopt_controller.py:2527-2532, :1937-1942) -- wave B
   const double grad = (ms ? bcast<12>(gsum) : bcast<13>(gsum)) / (double)N;

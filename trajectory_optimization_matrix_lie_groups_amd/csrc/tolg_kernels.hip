@@ -3370,7 +3370,7 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
     // wave-pair form, with k_backward3 behind it for the groups it hands back
     if constexpr (M == 6) {
       if (h->hc.grav == 0.0 && !al && P.N >= 8) {
-        hipLaunchKernelGGL((k_backward5<6>), grid, dim3(128), 0, st, P, it, ms);
+        hipLaunchKernelGGL((k_backward5<6>), dim3((P.Bp / 4 + 1) / 2), dim3(256), 0, st, P, it, ms);  // two groups per workgroup
         LAUNCH_CHECK();
         hipLaunchKernelGGL((k_backward3<6, false, false>), grid, blk, 0, st, P, it, ms | 4);
         LAUNCH_CHECK();
