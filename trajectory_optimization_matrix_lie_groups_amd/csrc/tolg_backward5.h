@@ -9,9 +9,10 @@
 // rocprofv3, 0.40-0.42 against 0.355 in the bench (two-wave workgroups, roles by wave index).  The two waves of a pair
 // are unequal (A: 180 vector instructions per knot, B: 350 on the critical path), so which waves share a SIMD matters;
 // the form below makes that exact -- four-wave workgroups, roles from the SIMD a wave finds itself on, one A and one B
-// per SIMD (tools/hwid_probe.hip) -- and is slower still (0.437 ms): two groups now share every barrier.  The pair is
-// paced by B's path plus what the exchanges and barriers leave exposed, and a second launch redoes the handed-back
-// groups; 17 % fewer cycles on B's path do not pay for that.
+// per SIMD (tools/hwid_probe.hip) -- and is slower still (0.437 ms): with a busy A wave on its SIMD and two groups on every
+// barrier, B's path is 4 010 cycles per knot (LDS round trips at the top and the tail of a step take 43 % of it), as long
+// as the single wave's whole knot.  What the second wave takes off B it gives back in LDS latency and shared issue slots,
+// and a second launch redoes the handed-back groups.
 //
 // Why.  k_backward3 is one wave per SIMD issuing 571 vector instructions per knot at 5.8 cycles each; two resident waves
 // issue at 4.4-4.5 per SIMD (profiles/r03_valu_issue_microbench.txt).  The half-column form of tolg_backward4.h got two
