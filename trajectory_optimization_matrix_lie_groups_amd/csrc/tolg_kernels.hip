@@ -2681,7 +2681,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
 // roll_step's linear form (round 2: one thread per trajectory, 3.9 ms per call -- half of a merit-search iteration).
 template <int M, int PK>
 __global__ __launch_bounds__(64) void k_expected_change(Params P) {
-  const Consts& C = *P.c;
+  const Consts& C = *P.c;  // generic pointer (note at DConsts)
   const int t = blockIdx.x * 64 + threadIdx.x;
   int b = t >> 2;
   const int q = t & 3;
@@ -2695,6 +2695,15 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
   const DynK DK = dynk_load(C);
   double c1 = 0, c2 = 0;
+  // the constant weight blocks of the quadratic model, in LDS: read from the constants in memory they were ~100 loads per
+  // knot on a chain that is nothing but load latencies
+  __shared__ double sW2[36], sP2[36], sR2[36];
+  if (threadIdx.x < 36) {
+    sW2[threadIdx.x] = 2.0 * C.W2[threadIdx.x]; sP2[threadIdx.x] = 2.0 * C.P2[threadIdx.x];
+    sR2[threadIdx.x] = (threadIdx.x < M * M) ? 2.0 * C.R[threadIdx.x] : 0.0;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): single-wave workgroup, LDS is in order
+  __builtin_amdgcn_wave_barrier();
   State So = roll_load_state(P, 0, vb, sB);
 #ifdef TOLG_STAMPS
   RStamps ST;
@@ -2704,7 +2713,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   // l_x e and e^T l_xx e with l_xx = blkdiag(l_xx11, 2 W2)
   auto state_terms = [&](int i, const double (&e)[12]) {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
-    const double* W2 = (i == N) ? C.P2 : C.W2;
+    const double* W2 = (i == N) ? sP2 : sW2;
 #pragma unroll
     for (int a = 0; a < 12; a++) c1 += bld(rR, REC_VR(b), FOFF(REC_LX + a)) * e[a];
 #pragma unroll
@@ -2712,7 +2721,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         c2 += e[a] * bld(rR, REC_VR(b), FOFF(REC_LXX + sym6(a, k))) * e[k];
-        c2 += e[6 + a] * 2.0 * W2[6 * a + k] * e[6 + k];
+        c2 += e[6 + a] * W2[6 * a + k] * e[6 + k];
       }
   };
   for (int i = 0; i < N; i++) {
@@ -2729,7 +2738,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
     for (int a = 0; a < M; a++) {
       c1 += bld(rR, REC_VR(b), FOFF(REC_LU + a)) * pr.du[a];
 #pragma unroll
-      for (int k = 0; k < M; k++) c2 += pr.du[a] * 2.0 * C.R[a * M + k] * pr.du[k];
+      for (int k = 0; k < M; k++) c2 += pr.du[a] * sR2[a * M + k] * pr.du[k];
       if (P.al_lb) c2 += pr.du[a] * bld(rR, REC_VR(b), FOFF(P.fLUU + a)) * pr.du[a];
     }
     Sn = Nx;
