@@ -191,6 +191,14 @@ int tolg_eval_knot(tolg_handle_t h, int32_t i, int32_t n, const double* d_x_q, c
 int tolg_rollout(tolg_handle_t h, int32_t ms, int32_t rollout_linear, double alpha, int32_t B,
                  double* d_xs_q_new, double* d_xs_xi_new, double* d_us_new, void* stream);
 
+/* Unit-parity entry point for the merit search's preparation: the linear alpha = 1 rollout and
+ * _expected_cost_change (traopt_controller.py:2550-2552, :2730-2737, :2756-2769) on the trajectory, records and
+ * gains tolg_linearize_backward(ms = 1) left in the workspace.  form 0: the statement-by-statement kernel
+ * (k_expected_change); 1: the ring form alone (k_expected_change_ring; d_flag[b] = 1 marks the trajectories it
+ * hands back, whose d_ecc entries are NaN); 2: the ring form with the hand-back behind it -- what a solve runs.
+ * out: d_ecc [B][2] (first-order, second-order term), d_flag [B] (may be NULL). */
+int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, double* d_ecc, int32_t* d_flag, void* stream);
+
 /* Timing hook for bench.py: HIP-event time (ms) and launch count of the dominant kernel
  * (backward sweep) accumulated since the last call with reset != 0.  Synchronises the recorded
  * events only. */

@@ -1,0 +1,133 @@
+"""The merit search's linear alpha = 1 rollout in its two forms (GPU, -m gpu): k_expected_change_ring -- the affine
+recursion in the backward sweep's lane map, inputs through an LDS ring -- against k_expected_change, which walks the
+reference's statements (traopt_controller.py:2550-2557, :2730-2737, :2756-2788), and both against the oracle.
+schedule="split" selects the statement-by-statement kernel alone; "auto" the ring form with the hand-back behind it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bridge as ob  # noqa: E402  (test infrastructure)
+from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR, TrackingProblem, workloads  # noqa: E402
+
+
+def _oracle_problem(p: TrackingProblem):
+    return ob.OracleProblem(p.kind, p.J, p.dt, p.Q, p.R, p.P, p.q_ref, p.xi_ref)
+
+
+def _rel(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _problem(kind, B, N):
+    if kind == "se3":
+        return workloads.se3_tracking(B, N=N, R_scale=1e-3)
+    if kind == "drone":
+        return workloads.drone_tracking(B, N=N, R_scale=1e-3)
+    prob, x0_q, x0_xi, us0 = workloads.so3_tracking(B, N=N)
+    return prob, x0_q, x0_xi, us0
+
+
+def _random_traj(prob, B, seed, spread):
+    rng = np.random.default_rng(seed)
+    N, m = prob.N, prob.m
+    xs_q = np.empty((B, N + 1, 4, 4)); xs_xi = np.empty((B, N + 1, 6)); us = rng.normal(size=(B, N, m)) * 0.3
+    for b in range(B):
+        for i in range(N + 1):
+            xs_q[b, i] = prob.q_ref[i] @ ob.se3_exp(rng.normal(size=6) * spread * (1 if prob.kind != "so3" else np.r_[1, 1, 1, 0, 0, 0]))
+            xs_xi[b, i] = prob.xi_ref[i] + rng.normal(size=6) * spread * (1 if prob.kind != "so3" else np.r_[1, 1, 1, 0, 0, 0])
+    if prob.kind == "so3":
+        us[:, :, 3:] = 0
+    return xs_q, xs_xi, us
+
+
+@pytest.mark.parametrize("kind,B,N", [("se3", 7, 33), ("se3", 64, 200), ("drone", 5, 60), ("drone", 12, 150), ("so3", 4, 40)])
+@pytest.mark.parametrize("spread", [0.02, 0.15])
+def test_ring_kernel_matches_statement_kernel_on_random_trajectories(kind, B, N, spread):
+    """The two kernels on the same records and gains (open trajectories with defects of size `spread`): first- and
+    second-order terms agree to rounding wherever the ring form keeps a trajectory; repeated launches are bitwise
+    reproducible; what it hands back, the statement kernel behind it fills in.  (The entry point poisons the LDS of
+    every CU with NaNs first: the statement kernel once filled its constant table AFTER inactive quads had left, and
+    passed wherever the previous launch had left the same table behind.)"""
+    prob, *_ = _problem(kind, 1, N)
+    xs_q, xs_xi, us = _random_traj(prob, B, seed=3 + N, spread=spread)
+    if B >= 5:  # two trajectories with rotation defects near pi: candidates for the hand-back
+        wild, _, _ = _random_traj(prob, B, seed=4 + N, spread=1.6)
+        xs_q[1], xs_q[4] = wild[1], wild[4]
+    solver = BatchedTrackingILQR(prob, B)
+    solver.linearize_backward(xs_q, xs_xi, us, ms=True)
+    es, _ = solver.expected_change(B, "statement")
+    er, flag = solver.expected_change(B, "ring")
+    er2, flag2 = solver.expected_change(B, "ring")
+    ea, _ = solver.expected_change(B, "auto")
+    torch.cuda.synchronize()
+    es, er, er2, ea, flag, flag2 = (t.cpu().numpy() for t in (es, er, er2, ea, flag, flag2))
+    np.testing.assert_array_equal(flag, flag2)
+    np.testing.assert_array_equal(er, er2)
+    keep = flag == 0
+    assert keep.sum() >= B // 2
+    assert np.isfinite(es).all()
+    scale = np.abs(es).max(axis=1, keepdims=True)
+    assert (np.abs(er[keep] - es[keep]) / scale[keep]).max() < 1e-11
+    assert np.isnan(er[~keep]).all()
+    np.testing.assert_array_equal(ea[~keep], es[~keep])
+    np.testing.assert_array_equal(ea[keep], er[keep])
+
+
+def _fit(solver, x0_q, x0_xi, us0, K, schedule):
+    r = solver.fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
+                         line_search=True, schedule=schedule)
+    torch.cuda.synchronize()
+    return r
+
+
+@pytest.mark.parametrize("kind,B,N", [("se3", 6, 50), ("se3", 9, 37), ("drone", 5, 60), ("so3", 4, 40)])
+def test_ring_form_matches_statement_form_and_oracle(kind, B, N):
+    """Same accepted step sizes, same costs (the two kernels differ by Exp/Log round trips and the order of two sums);
+    B not a multiple of 4 exercises the padded group, N not a multiple of 4 the ring's tail steps."""
+    K = 8
+    prob, x0_q, x0_xi, us0 = _problem(kind, B, N)
+    solver = BatchedTrackingILQR(prob, B)
+    ra = _fit(solver, x0_q, x0_xi, us0, K, "auto")
+    Ja, Aa, ia, ua = ra.J_hist.cpu().numpy().copy(), ra.alpha_hist.cpu().numpy().copy(), ra.iters.cpu().numpy().copy(), ra.us.cpu().numpy().copy()
+    rs = _fit(solver, x0_q, x0_xi, us0, K, "split")
+    Js, As, is_, us_ = rs.J_hist.cpu().numpy(), rs.alpha_hist.cpu().numpy(), rs.iters.cpu().numpy(), rs.us.cpu().numpy()
+    o = ob.fit_batch(_oracle_problem(prob), x0_q, x0_xi, us0, mode="ms", max_iter=K, line_search=True)
+    np.testing.assert_array_equal(is_, o["iters"], err_msg="statement form vs oracle")
+    np.testing.assert_array_equal(ia, o["iters"], err_msg="ring form vs oracle")
+    for b in range(B):
+        n = ia[b]
+        np.testing.assert_allclose(Aa[b, :n], As[b, :n], rtol=1e-14)
+        assert _rel(Ja[b, :n], Js[b, :n]) < 1e-10
+        assert _rel(Ja[b, :n], o["J_hist"][b, :n]) < 1e-8
+    assert _rel(ua, us_) < 1e-8
+    assert _rel(ua, o["us"]) < 1e-6
+
+
+def test_large_rotation_deviation_is_handed_back():
+    """An initial pose more than 3 rad away from the reference's first knots: the linear rollout's rotation deviation
+    leaves the range in which Log(Exp(v)) = v, the ring kernel flags the trajectory and the statement-by-statement
+    kernel behind it produces the result -- the same one as without the ring kernel, and the oracle's."""
+    B, N, K = 6, 40, 6
+    prob, x0_q, x0_xi, us0 = workloads.se3_tracking(B, N=N, R_scale=1e-3)
+    # trajectories 1, 3, 4: the reference's first pose turned by 3.1 rad about some axis; the others stay as they are
+    rng = np.random.default_rng(5)
+    for b in (1, 3, 4):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        x0_q[b] = prob.q_ref[0] @ ob.se3_exp(np.concatenate([3.1 * ax, rng.normal(size=3) * 0.2]))
+    solver = BatchedTrackingILQR(prob, B)
+    ra = _fit(solver, x0_q, x0_xi, us0, K, "auto")
+    Ja, ia, ua = ra.J_hist.cpu().numpy().copy(), ra.iters.cpu().numpy().copy(), ra.us.cpu().numpy().copy()
+    Aa = ra.alpha_hist.cpu().numpy().copy()
+    rs = _fit(solver, x0_q, x0_xi, us0, K, "split")
+    np.testing.assert_array_equal(ia, rs.iters.cpu().numpy())
+    o = ob.fit_batch(_oracle_problem(prob), x0_q, x0_xi, us0, mode="ms", max_iter=K, line_search=True)
+    np.testing.assert_array_equal(ia, o["iters"])
+    for b in range(B):
+        n = ia[b]
+        np.testing.assert_allclose(Aa[b, :n], rs.alpha_hist.cpu().numpy()[b, :n], rtol=1e-14)
+        assert _rel(Ja[b, :n], rs.J_hist.cpu().numpy()[b, :n]) < 1e-10
+        assert _rel(Ja[b, :n], o["J_hist"][b, :n]) < 1e-8
+    assert _rel(ua, o["us"]) < 1e-6

@@ -26,7 +26,7 @@ class Options(C.Structure):
 _lib = None
 SYMBOLS = ["tolg_workspace_bytes", "tolg_create", "tolg_destroy", "tolg_solve_batch", "tolg_solve_begin",
            "tolg_solve_iterate", "tolg_solve_iterate_until", "tolg_solve_end", "tolg_solve_peek", "tolg_solve_active_count", "tolg_set_al", "tolg_al_update", "tolg_eval_knot", "tolg_linearize_backward",
-           "tolg_rollout", "tolg_kernel_time", "tolg_enable_timing", "tolg_version", "tolg_selftest_series"]
+           "tolg_rollout", "tolg_expected_change", "tolg_kernel_time", "tolg_enable_timing", "tolg_version", "tolg_selftest_series"]
 
 
 def load():
@@ -72,6 +72,8 @@ def load():
     lib.tolg_linearize_backward.argtypes = [vp, C.c_int32, C.c_double, C.c_int32] + [dp] * 13 + [vp]
     lib.tolg_rollout.restype = C.c_int
     lib.tolg_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, C.c_int32, dp, dp, dp, vp]
+    lib.tolg_expected_change.restype = C.c_int
+    lib.tolg_expected_change.argtypes = [vp, C.c_int32, C.c_int32, dp, ip, vp]
     lib.tolg_kernel_time.restype = C.c_int
     lib.tolg_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -92,6 +92,7 @@ struct Params {
   int* ls_accept;      // [Bp]     accepted alpha index or -1
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
   int* k2_redo;        // [Bp/4]   groups of four whose sweep k_backward4 handed to k_backward3 (tolg_backward4.h)
+  int* ec_redo;        // [Bp]     trajectories k_expected_change_ring hands to k_expected_change (tolg_expected_change.h)
   // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
   const double* al_lb;      // [m] or null (= AL off)
   const double* al_ub;      // [m]
@@ -2679,7 +2680,8 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
 // MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
 // _expected_cost_change (:2756-2769), _update_defect_weight (:2774-2788).  Four lanes per trajectory, the step is
 // roll_step's linear form (round 2: one thread per trajectory, 3.9 ms per call -- half of a merit-search iteration).
-template <int M, int PK>
+// REDO: only the trajectories k_expected_change_ring (tolg_expected_change.h) handed back.
+template <int M, int PK, bool REDO = false>
 __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   const Consts& C = *P.c;  // generic pointer (note at DConsts)
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -2687,16 +2689,9 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   const int q = t & 3;
   const bool live = b < P.Bp;
   if (!live) b = P.Bp - 1;
-  if (!P.active[b]) return;  // quad-uniform
-  const bool writer = live && q == 0;
-  const int N = P.N;
-  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const size_t recStride = (size_t)P.recF * P.Bp;
-  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
-  const DynK DK = dynk_load(C);
-  double c1 = 0, c2 = 0;
   // the constant weight blocks of the quadratic model, in LDS: read from the constants in memory they were ~100 loads per
-  // knot on a chain that is nothing but load latencies
+  // knot on a chain that is nothing but load latencies.  Filled by the first 36 lanes of the wave BEFORE any quad
+  // leaves: a quad that is inactive (or, with REDO, not handed back) must still write its share of the table.
   __shared__ double sW2[36], sP2[36], sR2[36];
   if (threadIdx.x < 36) {
     sW2[threadIdx.x] = 2.0 * C.W2[threadIdx.x]; sP2[threadIdx.x] = 2.0 * C.P2[threadIdx.x];
@@ -2704,6 +2699,15 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): single-wave workgroup, LDS is in order
   __builtin_amdgcn_wave_barrier();
+  if (!P.active[b]) return;  // quad-uniform
+  if (REDO && !P.ec_redo[b]) return;
+  const bool writer = live && q == 0;
+  const int N = P.N;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const size_t recStride = (size_t)P.recF * P.Bp;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  const DynK DK = dynk_load(C);
+  double c1 = 0, c2 = 0;
   State So = roll_load_state(P, 0, vb, sB);
 #ifdef TOLG_STAMPS
   RStamps ST;
@@ -2759,6 +2763,8 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
   P.dweight[2 * b] = w;
   P.dweight[2 * b + 1] = w;
 }
+
+#include "tolg_expected_change.h"
 
 __global__ void k_ls_begin(Params P, int first_fit_iteration) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3135,8 +3141,10 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* ls_accept = c.take<int>(B);
   int* ls_slot = c.take<int>(B);
   int* k2_redo = c.take<int>(B / 4 + 1);
+  int* ec_redo = c.take<int>(B);
   if (P) {
     P->k2_redo = k2_redo;
+    P->ec_redo = ec_redo;
     P->slot_x = slot_x; P->slot_u = slot_u; P->Jtrial = Jtrial; P->dtrial = dtrial; P->ecc = ecc;
     P->dweight = dweight; P->ls_alpha = ls_alpha; P->ls_accept = ls_accept; P->ls_slot = ls_slot;
     P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
@@ -3511,7 +3519,14 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if (hipEventRecord(h->side_ev[0], st) != hipSuccess || hipStreamWaitEvent(h->side, h->side_ev[0], 0) != hipSuccess) return TOLG_E_LAUNCH;
       if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
         hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
-      else
+      else if (P.fA22 < 0 && opt->schedule != TOLG_SCHED_SPLIT) {
+        // the affine recursion in the backward sweep's lane map, inputs through an LDS ring (tolg_expected_change.h);
+        // behind it the statement-by-statement form for the trajectories it hands back (rotation deviations near pi)
+        if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true>), dim3(P.Bp / 4), dim3(64), 0, h->side, P);
+        else hipLaunchKernelGGL((k_expected_change_ring<M, false>), dim3(P.Bp / 4), dim3(64), 0, h->side, P);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
+      } else
         hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       LAUNCH_CHECK();
       if (hipEventRecord(h->side_ev[1], h->side) != hipSuccess) return TOLG_E_LAUNCH;
@@ -3758,6 +3773,64 @@ extern "C" int tolg_eval_knot(tolg_handle_t h, int32_t i, int32_t n, const doubl
   if (rc) return rc;
   hipLaunchKernelGGL(k_probe_export, dim3((n + 63) / 64), dim3(64), 0, st, P, i, d_f_q, d_f_xi, d_Fx, d_Fu, d_l, d_lx,
                      d_lxx, d_lu, d_luu, d_err);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_export_ecc(Params P, double* __restrict__ ecc, int* __restrict__ flag) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  if (ecc) { ecc[2 * b] = P.ecc[2 * b]; ecc[2 * b + 1] = P.ecc[2 * b + 1]; }
+  if (flag) flag[b] = P.ec_redo[b];
+}
+__global__ void k_clear_ecc(Params P) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.Bp) return;
+  P.ecc[2 * b] = __builtin_nan(""); P.ecc[2 * b + 1] = __builtin_nan(""); P.ec_redo[b] = 0;
+  P.dweight[2 * b] = 10.0; P.dweight[2 * b + 1] = 10.0;
+}
+// LDS is not cleared between launches: a kernel that reads LDS it has not written usually meets what the previous
+// launch of the same kernel left at the same offsets -- the right values -- and passes its tests.  The unit-parity entry
+// point below fills the LDS of every CU with NaNs first, so that such a read shows.
+__global__ __launch_bounds__(256) void k_poison_lds() {
+  __shared__ double junk[8192];
+  for (int k = threadIdx.x; k < 8192; k += 256) junk[k] = __builtin_nan("");
+  __syncthreads();
+  if (junk[(threadIdx.x * 33) & 8191] == 0.0) __builtin_trap();  // keeps the stores alive; never true
+}
+extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, double* d_ecc, int32_t* d_flag, void* stream) {
+  // works on what tolg_linearize_backward left in the workspace (trajectory, records, gains): not during a solve
+  if (!h || h->running || B < 1 || B > h->max_batch || form < 0 || form > 2) return TOLG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Params P = params_for(h, B);
+  const bool ring_ok = P.fA22 < 0 && h->prob.kind != TOLG_DYN_PENDULUM3D;
+  if (form != 0 && !ring_ok) return TOLG_E_ARG;
+  hipLaunchKernelGGL(k_clear_ecc, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_poison_lds, dim3(2048), dim3(256), 0, st);
+  LAUNCH_CHECK();
+  const dim3 gq((P.Bp * 4 + 63) / 64), gr(P.Bp / 4), blk(64);
+  if (form == 0) {
+    if (P.m == 4) hipLaunchKernelGGL((k_expected_change<4, 0>), gq, blk, 0, st, P);
+    else if (h->prob.kind == TOLG_DYN_PENDULUM3D) hipLaunchKernelGGL((k_expected_change<6, 1>), gq, blk, 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change<6, 0>), gq, blk, 0, st, P);
+  } else {
+    const bool grav = h->hc.grav != 0.0;
+    if (P.m == 4) {
+      if (grav) hipLaunchKernelGGL((k_expected_change_ring<4, true>), gr, blk, 0, st, P);
+      else hipLaunchKernelGGL((k_expected_change_ring<4, false>), gr, blk, 0, st, P);
+    } else {
+      if (grav) hipLaunchKernelGGL((k_expected_change_ring<6, true>), gr, blk, 0, st, P);
+      else hipLaunchKernelGGL((k_expected_change_ring<6, false>), gr, blk, 0, st, P);
+    }
+    LAUNCH_CHECK();
+    if (form == 2) {
+      if (P.m == 4) hipLaunchKernelGGL((k_expected_change<4, 0, true>), gq, blk, 0, st, P);
+      else hipLaunchKernelGGL((k_expected_change<6, 0, true>), gq, blk, 0, st, P);
+    }
+  }
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_export_ecc, dim3((B + 63) / 64), dim3(64), 0, st, P, d_ecc, d_flag);
   LAUNCH_CHECK();
   return 0;
 }

@@ -381,6 +381,19 @@ class BatchedTrackingILQR:
         _capi.check(rc, "tolg_rollout")
         return xs_q, xs_xi, us
 
+    def expected_change(self, B, form="auto"):
+        """_expected_cost_change of the linear alpha = 1 rollout (traopt_controller.py:2550-2552, :2756-2769) with the
+        records and gains of the preceding linearize_backward(ms=True) call.  form: "statement" (the kernel that walks
+        the reference's statements), "ring" (the affine recursion alone; flag marks what it hands back, NaN there),
+        "auto" (ring + hand-back: what a solve runs).  Returns (ecc [B, 2], flag [B])."""
+        ecc = torch.empty(B, 2, dtype=torch.float64, device=self.device)
+        flag = torch.zeros(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tolg_expected_change(self._h, {"statement": 0, "ring": 1, "auto": 2}[form], B, _ptr(ecc),
+                                               _ptr(flag), self._stream())
+        _capi.check(rc, "tolg_expected_change")
+        return ecc, flag
+
     # ------------------------------------------------------------------------------------------
     def enable_timing(self, on=True):
         self.lib.tolg_enable_timing(self._h, int(on))
