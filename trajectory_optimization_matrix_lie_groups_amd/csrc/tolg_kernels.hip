@@ -93,6 +93,13 @@ struct Params {
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
   int* k2_redo;        // [Bp/4]   groups of four whose sweep k_backward4 handed to k_backward3 (tolg_backward4.h)
   int* ec_redo;        // [Bp]     trajectories k_expected_change_ring hands to k_expected_change (tolg_expected_change.h)
+  // line search, round 3 form: the stages roll out only (quad rollouts over a compacted list of the undecided
+  // trajectories), costs and defects of the candidates are evaluated in parallel over the knots
+  int* ls_list;        // [2][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
+  int* ls_count;       // [2]      ... the stage's kernels still read the current one
+  int* ls_pos;         // [2][Bp]  position of a trajectory on its list: the quad form keeps a stage's candidates densely, by position
+  double* LSC;         // [NSLOT][N+1][Bp] stage costs of the candidates
+  double* LSD;         // [NSLOT][N][Bp]   squared defects of the candidates (MS)
   // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
   const double* al_lb;      // [m] or null (= AL off)
   const double* al_ub;      // [m]
@@ -2418,6 +2425,15 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 // slot buffers), then the first alpha that passes -- in the reference's order -- wins.
 // ------------------------------------------------------------------------------------------------
 TOLG_DEV double ls_alpha_k(int k) { return pow(1.1, -(double)(k * k)); }
+// A wide stage (several alphas of the trajectories still undecided) has two forms, chosen on the device from the number
+// of undecided trajectories n (list `list` of the previous select): four lanes per (trajectory, alpha) over the
+// compacted list + parallel evaluation (k_rollout_ls, k_ls_eval, k_ls_sum) while n * alphas <= LS_QUAD_MAX -- a few
+// hundred waves, each at the speed of a lone rollout --, one thread per (trajectory, alpha) with cost and defect on the
+// chain (k_rollout_eval_t) beyond: 64 waves per alpha whatever n is.  Measured at 4096 x 200, 12 alphas: quad form
+// 0.45 + 0.15 ms at n ~ 600, 1.36 + 0.39 ms at n ~ 2500; thread form 1.3-1.4 ms for any n.  Every kernel of a stage is
+// launched; the ones whose form is not in turn leave at once.
+enum { LS_QUAD_MAX = 20000 };
+TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots) { return list < 0 || P.ls_count[list] * nslots <= LS_QUAD_MAX; }
 
 // stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738)
 template <int M>
@@ -2464,10 +2480,11 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
 // wide stages (many alphas per trajectory: 64 waves per alpha keep a 12-alpha stage within one wave per SIMD; the
 // quad form below takes four times the waves and runs the first, one-alpha stage in 0.68 instead of 1.15 ms)
 template <int M, bool MS, bool LINEAR>
-__global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nslots) {
+__global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nslots, int list) {
   const Consts& C = *P.c;
   const int b = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   if (b >= P.Bp || slot >= nslots) return;
+  if (list >= -1 && ls_quad_form(P, list, nslots)) return;  // list = -2: unconditional (TOLG_LS_FUSED_EVAL)
   if (!P.active[b] || P.ls_accept[b] >= 0) return;
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai);
@@ -2677,6 +2694,173 @@ __global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslot
   }
 }
 
+// ---- line-search stages, round 3 form -----------------------------------------------------------------------------
+// A stage is three launches: (1) k_rollout_ls -- the closed-loop rollouts alone, the quad form of K3 (roll_step with
+// STORE), one quad per (undecided trajectory, alpha), the undecided trajectories taken from a compacted list so that a
+// wide stage of a few stragglers is a few waves and not a sweep over the batch; (2) k_ls_eval -- stage costs and (MS)
+// squared defects of the stored candidates, one thread per (trajectory, knot, alpha): none of it depends on the
+// rollout chain, on which k_rollout_eval carried it (a second Log, a cost with its own Log, per knot: stage 1 took
+// 0.68 ms SS / 1.10 ms MS against 0.33 ms for the bare rollout); (3) k_ls_sum -- the sums in knot order, the order of
+// _trajectory_cost / _compute_defect_norm (traopt_controller.py:2742-2754, :2790-2821).
+#ifdef TOLG_LS_OCC2
+#define TOLG_LS_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define TOLG_LS_ATTR
+#endif
+template <int M, bool MS, bool LINEAR, int PK>
+__global__ __launch_bounds__(64) TOLG_LS_ATTR void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
+  const Consts& C = *P.c;  // generic pointer (note at DConsts)
+  const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
+  const int quad = t >> 2, q = t & 3;
+  if (slot >= nslots) return;
+  int b;
+  bool live;
+  if (list >= 0) {
+    // the undecided trajectories of the previous stage's select (k_ls_select), in no particular order; one alpha per
+    // wave.  (Four trajectories x four alphas per wave, so that the four quads of a trajectory share their gain and
+    // nominal-state loads, was measured: slower -- SS 343 -> 307 it/s; a wave then mixes step sizes whose rollouts take
+    // different branches of the series gates.)
+    const int n = P.ls_count[list];
+    if (n * nslots > LS_QUAD_MAX) return;  // the thread form's turn (ls_quad_form)
+    if ((quad & ~15) >= n) return;  // wave-uniform: none of this wave's 16 quads has work
+    live = quad < n;
+    b = P.ls_list[(size_t)list * P.Bp + (live ? quad : n - 1)];  // idle quads replay the last entry and store nothing
+  } else {
+    live = quad < P.Bp;
+    b = live ? quad : P.Bp - 1;
+    if (!P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
+  }
+  const bool writer = live && q == 0;
+  const int N = P.N, ai = a0 + slot;
+  const double alpha = ls_alpha_k(ai);
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  // where the candidate goes: the candidate arrays at b (a one-alpha stage), or slot `slot` at the trajectory's POSITION
+  // on the list -- dense, so that the stores of a wave fill whole lines and k_ls_eval reads whole lines (kept at b, a
+  // few hundred undecided trajectories scattered over the batch cost eight times their bytes, here and in the evaluation)
+  const unsigned vs = (list >= 0) ? (unsigned)(live ? quad : 0) * 8u : vb;
+  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp;
+  double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
+  double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, Sn);
+  const DynK DK = dynk_load(C);
+  State So = roll_load_state(P, 0, vb, sB);
+#ifdef TOLG_STAMPS
+  RStamps ST;
+  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+  ST.t = __builtin_amdgcn_s_memtime();
+#endif
+  double un[M];
+  for (int i = 0; i < N; i++) {
+    State Sx = So;  // nominal state of knot i; knot i + 1 is requested before the step needs it
+    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
+    __builtin_amdgcn_sched_barrier(0);
+    // single shooting steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
+    Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sx, Sn, un,
+                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+    if (writer) {
+      __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB);
+#pragma unroll
+      for (int a = 0; a < M; a++) bst(rSU, vs, a * sB, un[a]);
+      store_state_b(mkbuf(sx + stStride * (i + 1), 13 * sB), vs, sB, Sn);
+    }
+  }
+}
+// the first try of the MS merit search, alpha = 1: the factors of :2713-2716 are the identity (note at the record
+// layout), the step is x^+ = f(x^, u^) -- K3's ALPHA1 form, written straight into the candidate arrays
+template <int M, int PK>
+__global__ __launch_bounds__(64) void k_rollout_ls1(Params P) {
+  const Consts& C = *P.c;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  int b = t >> 2;
+  const int q = t & 3;
+  const bool live = b < P.Bp;
+  if (!live) b = P.Bp - 1;
+  if (!P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
+  const bool writer = live && q == 0;
+  const int N = P.N;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  if (writer) store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
+  const DynK DK = dynk_load(C);
+  State So = roll_load_state(P, 0, vb, sB);
+#ifdef TOLG_STAMPS
+  RStamps ST;
+  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
+  ST.t = __builtin_amdgcn_s_memtime();
+#endif
+  double un[M];
+  for (int i = 0; i < N; i++) {
+    State Sx = So;
+    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
+    __builtin_amdgcn_sched_barrier(0);
+    Sn = roll_step<M, false, true, PK, true>(P, C, DK, i, b, q, writer, vb, sB, 1.0, Sx, Sn, un,
+                                             [&](RollIn<M>& R) { roll_load<M, true>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+  }
+}
+
+// stage cost l(x^_i, u^_i) (traopt_cost.py:675-738) and, MS, the squared defect
+// |Log(x^_{i+1}^-1 f_q(x^_i, u^_i))|^2 + |f_xi - xi^_{i+1}|^2 (:2790-2812) of every stored candidate of the stage
+template <int M, bool MS>
+__global__ __launch_bounds__(256) void k_ls_eval(Params P, int nslots, int direct, int list) {
+  const Consts& C = *P.c;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int slot = blockIdx.y, N = P.N;
+  if (slot >= nslots || t >= (size_t)(N + 1) * P.Bp) return;
+  // e: where the candidate lies (its position on the list, or b itself for a stage that runs on the flags)
+  const int e = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  int b = e;
+  if (list >= 0) {
+    const int n = P.ls_count[list];
+    if (n * nslots > LS_QUAD_MAX || e >= n) return;
+    b = P.ls_list[(size_t)list * P.Bp + e];
+  } else if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp;
+  const double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
+  const double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
+  const State S = load_state(P, sx, i, e);
+  double u[M];
+#pragma unroll
+  for (int a = 0; a < M; a++) u[a] = (i < N) ? su[UIDX(a, i, e)] : 0.0;
+  P.LSC[((size_t)slot * (N + 1) + i) * P.Bp + e] = knot_cost<M>(P, C, i, b, S, u, i == N);
+  if constexpr (MS) {
+    if (i < N) {
+      const State Nx = load_state(P, sx, i + 1, e), Fn = dyn_f<M>(C, S, u);
+      V3 dw, dv;
+      se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+      const V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
+      P.LSD[((size_t)slot * N + i) * P.Bp + e] = dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
+    }
+  }
+}
+template <bool MS>
+__global__ void k_ls_sum(Params P, int a0, int nslots, int list) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = t % P.Bp, slot = t / P.Bp, N = P.N;
+  if (slot >= nslots) return;
+  int b = e;
+  if (list >= 0) {
+    const int n = P.ls_count[list];
+    if (n * nslots > LS_QUAD_MAX || e >= n) return;
+    b = P.ls_list[(size_t)list * P.Bp + e];
+  } else if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  const double* c = P.LSC + (size_t)slot * (N + 1) * P.Bp + e;
+  const double* d = P.LSD + (size_t)slot * N * P.Bp + e;
+  double J = 0, d2 = 0;
+  int i = 0;
+  for (; i + 16 <= N; i += 16) {  // fixed order; the loads go out sixteen knots at a time (k_reduce)
+    double cc[16], dd[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { cc[k] = c[(size_t)(i + k) * P.Bp]; dd[k] = MS ? d[(size_t)(i + k) * P.Bp] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { J += cc[k]; d2 += dd[k]; }
+  }
+  for (; i < N; i++) { J += c[(size_t)i * P.Bp]; if (MS) d2 += d[(size_t)i * P.Bp]; }
+  J += c[(size_t)N * P.Bp];
+  P.Jtrial[(size_t)b * 20 + a0 + slot] = J;
+  P.dtrial[(size_t)b * 20 + a0 + slot] = sqrt(d2);
+}
+
 // MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
 // _expected_cost_change (:2756-2769), _update_defect_weight (:2774-2788).  Four lanes per trajectory, the step is
 // roll_step's linear form (round 2: one thread per trajectory, 3.9 ms per call -- half of a merit-search iteration).
@@ -2768,6 +2952,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
 
 __global__ void k_ls_begin(Params P, int first_fit_iteration) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < 2) P.ls_count[b] = 0;
   if (b >= P.Bp) return;
   P.ls_accept[b] = -1;
   P.ls_slot[b] = -1;
@@ -2776,8 +2961,9 @@ __global__ void k_ls_begin(Params P, int first_fit_iteration) {
 }
 
 // first alpha (in the reference's order) of this stage that passes the acceptance test
+// ... and the trajectories that stay undecided go on list `out` (compacted, for the next stage's rollouts)
 template <bool MS>
-__global__ void k_ls_select(Params P, int a0, int nslots) {
+__global__ void k_ls_select(Params P, int a0, int nslots, int out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b] || P.ls_accept[b] >= 0) return;
   const double J0 = P.Jc[b], dn = P.dn[b];
@@ -2796,23 +2982,30 @@ __global__ void k_ls_select(Params P, int a0, int nslots) {
     }
     if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = s; return; }
   }
+  const int pos = atomicAdd(&P.ls_count[out], 1);
+  P.ls_list[(size_t)out * P.Bp + pos] = b;
+  P.ls_pos[(size_t)out * P.Bp + b] = pos;
 }
 
-__global__ void k_ls_copy(Params P) {
+// the accepted candidate of a wide stage -> the candidate arrays.  list / nslots: the stage's list and width -- the quad
+// form kept its candidates by list position, the thread form by trajectory (ls_quad_form)
+__global__ void k_ls_copy(Params P, int list, int nslots) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)(P.N + 1) * P.Bp) return;
   const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
   const int s = P.ls_slot[b];
   if (s < 0 || !P.active[b]) return;
+  const int e = (list >= 0 && ls_quad_form(P, list, nslots)) ? P.ls_pos[(size_t)list * P.Bp + b] : b;
   const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)P.m * P.Bp;
   const double* sx = P.slot_x + (size_t)s * stStride * (P.N + 1);
   const double* su = P.slot_u + (size_t)s * uStride * P.N;
-  for (int c = 0; c < 13; c++) P.cand[SIDX(c, i, b)] = sx[SIDX(c, i, b)];
+  for (int c = 0; c < 13; c++) P.cand[SIDX(c, i, b)] = sx[SIDX(c, i, e)];
   if (i < P.N)
-    for (int c = 0; c < P.m; c++) P.cand_u[UIDX(c, i, b)] = su[UIDX(c, i, b)];
+    for (int c = 0; c < P.m; c++) P.cand_u[UIDX(c, i, b)] = su[UIDX(c, i, e)];
 }
-__global__ void k_ls_clear_slot(Params P) {
+__global__ void k_ls_clear_slot(Params P, int reset_list) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) P.ls_count[reset_list] = 0;  // the list the NEXT stage's select fills (this stage's rollouts have read it)
   if (b < P.Bp) P.ls_slot[b] = -1;
 }
 // trajectories without an acceptable step: callback with the unchanged cost, then stop
@@ -3142,9 +3335,15 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* ls_slot = c.take<int>(B);
   int* k2_redo = c.take<int>(B / 4 + 1);
   int* ec_redo = c.take<int>(B);
+  int* ls_list = c.take<int>(2 * B);
+  int* ls_count = c.take<int>(64);
+  int* ls_pos = c.take<int>(2 * B);
+  double* LSC = c.take<double>((size_t)NSLOT * (N + 1) * B);
+  double* LSD = c.take<double>((size_t)NSLOT * N * B);
   if (P) {
     P->k2_redo = k2_redo;
     P->ec_redo = ec_redo;
+    P->ls_list = ls_list; P->ls_count = ls_count; P->ls_pos = ls_pos; P->LSC = LSC; P->LSD = LSD;
     P->slot_x = slot_x; P->slot_u = slot_u; P->Jtrial = Jtrial; P->dtrial = dtrial; P->ecc = ecc;
     P->dweight = dweight; P->ls_alpha = ls_alpha; P->ls_accept = ls_accept; P->ls_slot = ls_slot;
     P->c = cc; P->ref = ref; P->cur = cur; P->cur_u = cur_u; P->cand = cand; P->cand_u = cand_u;
@@ -3451,40 +3650,76 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
   LAUNCH_CHECK();
   return 0;
 }
+// One stage of the speculative line search: alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.
+// stage = 0, 1, 2 ...: stage 0 takes the undecided trajectories from the flags (all active ones), stage s > 0 from the
+// list select s - 1 compacted (lists alternate: select s fills list s & 1 while this stage's kernels read the other).
+// A one-alpha stage writes its candidate in place (no slot, no copy).  TOLG_LS_FUSED_EVAL (environment, read once):
+// the round-2 form, cost and defect on the rollout chain (k_rollout_eval / k_rollout_eval_t) -- for A/B timing.
+static bool ls_fused_eval() {
+  static const bool v = [] { const char* e = getenv("TOLG_LS_FUSED_EVAL"); return e && e[0] == '1'; }();
+  return v;
+}
 template <int M, bool MS>
-static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int a0, int n, int linear,
+static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int stage, int a0, int n, int linear,
                         hipEvent_t before_select = nullptr) {
-  // alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.  A one-alpha stage writes its candidate in
-  // place (no slot, no copy); a trajectory that has accepted leaves the later stages at once.
   const int direct = n == 1;
   if (n > NSLOT) return TOLG_E_ARG;
-  if (!direct) {
+  const bool pend = M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D;
+  const int list_in = stage == 0 ? -1 : (stage - 1) & 1, list_out = stage & 1;
+  if (ls_fused_eval()) {
     Timed t(h, st, 1);
-    dim3 grid((P.Bp + 63) / 64, n), blk(64);  // one thread per (trajectory, alpha)
-    if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n);
-    else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n);
+    if (!direct) {
+      dim3 grid((P.Bp + 63) / 64, n), blk(64);  // one thread per (trajectory, alpha)
+      if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n, -2);
+      else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n, -2);
+    } else {
+      dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per trajectory
+      if (pend) {
+        if (linear) hipLaunchKernelGGL((k_rollout_eval<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct);
+        else hipLaunchKernelGGL((k_rollout_eval<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct);
+      } else {
+        if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true, 0>), grid, blk, 0, st, P, a0, n, direct);
+        else hipLaunchKernelGGL((k_rollout_eval<M, MS, false, 0>), grid, blk, 0, st, P, a0, n, direct);
+      }
+    }
     LAUNCH_CHECK();
   } else {
     Timed t(h, st, 1);
-    dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per trajectory
-    if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
-      if (linear) hipLaunchKernelGGL((k_rollout_eval<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct);
-      else hipLaunchKernelGGL((k_rollout_eval<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct);
-    } else {
-      if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true, 0>), grid, blk, 0, st, P, a0, n, direct);
-      else hipLaunchKernelGGL((k_rollout_eval<M, MS, false, 0>), grid, blk, 0, st, P, a0, n, direct);
+    if (!direct) {  // the thread form of a wide stage: runs when the list is long (ls_quad_form), leaves at once otherwise
+      dim3 grid((P.Bp + 63) / 64, n), blk(64);
+      if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n, list_in);
+      else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n, list_in);
+      LAUNCH_CHECK();
     }
+    {
+      dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per (trajectory, alpha)
+      if (MS && direct && a0 == 0 && !linear) {
+        if (pend) hipLaunchKernelGGL((k_rollout_ls1<6, 1>), grid, blk, 0, st, P);
+        else hipLaunchKernelGGL((k_rollout_ls1<M, 0>), grid, blk, 0, st, P);
+      } else if (pend) {
+        if (linear) hipLaunchKernelGGL((k_rollout_ls<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
+        else hipLaunchKernelGGL((k_rollout_ls<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
+      } else {
+        if (linear) hipLaunchKernelGGL((k_rollout_ls<M, MS, true, 0>), grid, blk, 0, st, P, a0, n, direct, list_in);
+        else hipLaunchKernelGGL((k_rollout_ls<M, MS, false, 0>), grid, blk, 0, st, P, a0, n, direct, list_in);
+      }
+      LAUNCH_CHECK();
+    }
+    const size_t nn = (size_t)(P.N + 1) * P.Bp;
+    hipLaunchKernelGGL((k_ls_eval<M, MS>), dim3((unsigned)((nn + 255) / 256), n), dim3(256), 0, st, P, n, direct, list_in);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_ls_sum<MS>), dim3((unsigned)(((size_t)P.Bp * n + 63) / 64)), dim3(64), 0, st, P, a0, n, list_in);
     LAUNCH_CHECK();
   }
   if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
-  hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n);
+  hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n, list_out);
   LAUNCH_CHECK();
   if (!direct) {
     size_t nn = (size_t)(P.N + 1) * P.Bp;
-    hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, ls_fused_eval() ? -1 : list_in, n);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
+  hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, list_out ^ 1);
   LAUNCH_CHECK();
   return 0;
 }
@@ -3534,11 +3769,11 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       // of the trajectories still undecided -- iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20
       // (:2472).  Measured: the merit search of this workload rarely accepts the first alpha, and one stage of 19
       // took 5.2 ms against 3 x 0.7.
-      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
-      if ((rc = run_ls_stage<M, true>(h, P, st, 1, 4, opt->rollout_linear))) return rc;
-      if ((rc = run_ls_stage<M, true>(h, P, st, 5, 8, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear))) return rc;
       if (!so3_family(h->prob.kind))
-        if ((rc = run_ls_stage<M, true>(h, P, st, 13, 7, opt->rollout_linear))) return rc;
+        if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, opt->rollout_linear))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
     }
@@ -3559,8 +3794,8 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     if ((rc = run_backward<M>(h, P, st, it, 0))) return rc;
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
-    if ((rc = run_ls_stage<M, false>(h, P, st, 0, 1, opt->rollout_linear))) return rc;
-    if ((rc = run_ls_stage<M, false>(h, P, st, 1, NALPHA_SS - 1, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 1, 1, NALPHA_SS - 1, opt->rollout_linear))) return rc;
     hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
     if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0))) return rc;
