@@ -51,11 +51,12 @@ struct Consts {
 // prefetches on vmcnt.  Cold kernels keep the generic pointer: with a few hundred invariant scalar
 // loads hoisted out of their knot loops they would only spill SGPRs.
 // F_u's constants (Bt / Bb: fu_entry, dynk_load) are read through the GENERIC pointer everywhere, once, ahead of
-// the knot loops, and pinned in vector registers / LDS: reading them through this view inside k_rollout_eval's knot
-// loop gave wrong costs and memory-aperture faults in round 2 (profiles/r02_as4_cold_kernel_bisect.md; the ISA of
-// the failing build was re-read in round 3 -- scalar tuple s[8:23] loaded ahead of the loop, copied to AGPRs by
-// v_accvgpr_write inside it, nothing found that overwrites it -- and the cause is still open), so no hot kernel
-// depends on that construct any more.
+// the knot loops, and pinned in vector registers / LDS: reading them through this view inside the knot loop of
+// k_rollout_eval (the round-2 line-search kernel, cost and defect on the rollout chain; retired in round 3 -- the
+// stages now run k_rollout_ls / k_rollout_eval_t on the generic pointer) gave wrong costs and memory-aperture faults
+// (profiles/r02_as4_cold_kernel_bisect.md; the ISA of the failing build was re-read in round 3 -- scalar tuple
+// s[8:23] loaded ahead of the loop, copied to AGPRs by v_accvgpr_write inside it, nothing found that overwrites it --
+// and the cause is still open), so no kernel depends on that construct.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(4))) Consts DConsts;
 #else
@@ -1664,7 +1665,7 @@ TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const dou
   // where it does not (diagonal inertia: every reference script) it is applied WITHOUT being formed -- with
   // J = blkdiag(Ib, Jv), (coadjoint([v, w]) J + G) [a; c] = [(Ib w) x a - v x (Ib a) + m v x c - w x (Jv c);
   // m v x a - v x (Jv c)] (a22_build), six cross products instead of a 36-entry matrix in registers: the linear
-  // rollouts of the merit search (k_expected_change, k_rollout_eval<LINEAR>) spilled 160-470 registers to scratch with
+  // rollouts of the merit search (k_expected_change, the LINEAR line-search rollouts) spilled 160-470 registers to scratch with
   // the matrix form, 4.2 ms per k_expected_change call at 4096 x 200.
   double he[6] = {0, 0, 0, 0, 0, 0};
   if (P.fA22 < 0) {
@@ -2421,8 +2422,8 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 // Line search.  The reference tries alpha_k = 1.1^(-k^2) one after the other with a full rollout +
 // trajectory cost each (SS: traopt_controller.py:1972-1990, accept J_new < J_opt; MS:
 // :2549-2590, Armijo test on the merit J + w ||d||).  Here a stage evaluates several alphas of
-// every still-undecided trajectory at once (one thread per (trajectory, alpha), candidates kept in
-// slot buffers), then the first alpha that passes -- in the reference's order -- wins.
+// every still-undecided trajectory at once (candidates kept in slot buffers), then the first alpha
+// that passes -- in the reference's order -- wins.  Stage forms: run_ls_stage.
 // ------------------------------------------------------------------------------------------------
 TOLG_DEV double ls_alpha_k(int k) { return pow(1.1, -(double)(k * k)); }
 // A wide stage (several alphas of the trajectories still undecided) has two forms, chosen on the device from the number
@@ -2476,15 +2477,15 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
   return l;
 }
 
-// one thread per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm -- the form of the
-// wide stages (many alphas per trajectory: 64 waves per alpha keep a 12-alpha stage within one wave per SIMD; the
-// quad form below takes four times the waves and runs the first, one-alpha stage in 0.68 instead of 1.15 ms)
+// one thread per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm on the chain -- the
+// form of a wide stage with MANY undecided trajectories (64 waves per alpha keep a 12-alpha stage within one wave per
+// SIMD whatever their number; ls_quad_form decides on the device, the quad form -- k_rollout_ls -- takes the short lists)
 template <int M, bool MS, bool LINEAR>
 __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nslots, int list) {
   const Consts& C = *P.c;
   const int b = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   if (b >= P.Bp || slot >= nslots) return;
-  if (list >= -1 && ls_quad_form(P, list, nslots)) return;  // list = -2: unconditional (TOLG_LS_FUSED_EVAL)
+  if (ls_quad_form(P, list, nslots)) return;  // the quad form's turn
   if (!P.active[b] || P.ls_accept[b] >= 0) return;
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai);
@@ -2569,146 +2570,16 @@ __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nsl
   P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
 }
 
-// stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738), this lane's share: the four lanes of a trajectory
-// split the rows of the weight matrices (lane q: rows q and q + 4), every lane keeps a partial sum over the whole
-// horizon and the quad adds its four partials once, at the end.  The lane's weight rows are read once, ahead of the
-// knot loop (QuadW): inside it they were ~30 vector loads per knot on the sequential chain.
-template <int M>
-struct QuadW { double w1[2][6], w2[2][6], r[2][M]; };
-template <int M>
-TOLG_DEV QuadW<M> quadw_load(const Consts& C, int q, bool term) {
-  QuadW<M> W;
-  const bool so3 = so3_family(C.kind);  // the SO3 terminal cost is weighted with Q (App. C-Q3)
-  const double* W1 = (term && !so3) ? C.P1 : C.W1;
-  const double* W2 = (term && !so3) ? C.P2 : C.W2;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int a = q + 4 * h, a6 = a < 6 ? a : 0, aM = a < M ? a : 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { W.w1[h][k] = (a < 6) ? W1[6 * a6 + k] : 0.0; W.w2[h][k] = (a < 6) ? W2[6 * a6 + k] : 0.0; }
-#pragma unroll
-    for (int k = 0; k < M; k++) W.r[h][k] = (!term && a < M) ? C.R[aM * M + k] : 0.0;
-  }
-  return W;
-}
-template <int M>
-TOLG_DEV double knot_cost_q(const Params& P, const QuadW<M>& W, int i, int b, int q, const State& S, const double (&u)[M], bool term) {
-  const double* r = P.ref + 13 * (size_t)i;
-  Pose Xr;
-  Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
-  Xr.t = v3(r[4], r[5], r[6]);
-  V3 ew, ev;
-  se3_log_fast(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
-  const double e[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
-  const double ve[6] = {S.w.x - r[7], S.w.y - r[8], S.w.z - r[9], S.v.x - r[10], S.v.y - r[11], S.v.z - r[12]};
-  double l = 0;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int a = q + 4 * h;  // rows q (every lane) and q + 4 (lanes 0, 1); rows past the matrix carry zero weights
-    double s1 = 0, s2 = 0, s3 = 0, ea = 0, va = 0, ua = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { s1 += W.w1[h][k] * e[k]; s2 += W.w2[h][k] * ve[k]; ea = (k == a) ? e[k] : ea; va = (k == a) ? ve[k] : va; }
-#pragma unroll
-    for (int k = 0; k < M; k++) { s3 += W.r[h][k] * u[k]; ua = (k == a) ? u[k] : ua; }
-    l += ea * s1 + va * s2 + ua * s3;
-    if (!term && P.al_lb && a < M) {
-      const int bs = b < P.B ? b : P.B - 1;
-      const double* lam = P.al_lambda + ((size_t)bs * P.N + i) * 2 * M;
-      const double* imu = P.al_imu + ((size_t)bs * P.N + i) * 2 * M;
-      const double g1 = P.al_lb[a] - ua, g2 = ua - P.al_ub[a];
-      l += lam[a] * g1 + lam[M + a] * g2 + 0.5 * (g1 * imu[a] * g1 + g2 * imu[M + a] * g2);
-    }
-  }
-  return l;
-}
-TOLG_DEV double quad_sum(double x) { return ((quad_bcast<0>(x) + quad_bcast<1>(x)) + quad_bcast<2>(x)) + quad_bcast<3>(x); }
-
-// four lanes per (trajectory, slot): rollout with alpha_{a0+slot}, its cost and (MS) defect norm.  The step is
-// roll_step (the quad rollout of K3: gain product split by row pairs, series forms of Exp / Log); round 2 ran one
-// thread per (trajectory, slot) -- 64 waves at 4096 trajectories, ~1.15 ms per stage whatever the number of alphas
-// (profiles/r03_mid_kernel_stats_ss.csv) -- which made single shooting 4.7 ms per iteration.
-template <int M, bool MS, bool LINEAR, int PK>
-__global__ __launch_bounds__(64) void k_rollout_eval(Params P, int a0, int nslots, int direct) {
-  const Consts& C = *P.c;  // generic pointer (note at DConsts)
-  const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
-  int b = t >> 2;
-  const int q = t & 3;
-  const bool live = b < P.Bp;  // quads past the batch replay the last trajectory (DPP needs whole quads) and store nothing
-  if (!live) b = P.Bp - 1;
-  if (slot >= nslots || !P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
-  const bool writer = live && q == 0;
-  const int N = P.N, ai = a0 + slot;
-  const double alpha = ls_alpha_k(ai);
-  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp;
-  // direct: the one alpha of this stage writes straight into the candidate arrays (the first try, which most
-  // iterations accept: no slot, no copy); otherwise slot `slot`
-  double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
-  double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
-  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
-  if (writer) store_state_b(mkbuf(sx, 13 * sB), vb, sB, Sn);
-  const DynK DK = dynk_load(C);
-  const QuadW<M> QW = quadw_load<M>(C, q, false);
-  double J = 0, d2 = 0;
-  State So = roll_load_state(P, 0, vb, sB);
-#ifdef TOLG_STAMPS
-  RStamps ST;
-  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
-  ST.t = __builtin_amdgcn_s_memtime();
-#endif
-  for (int i = 0; i < N; i++) {
-    State Sx = So;  // nominal state of knot i; knot i + 1 is requested before the step needs it
-    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
-    __builtin_amdgcn_sched_barrier(0);
-    double un[M];
-    RollProbe<M> pr;
-    // single shooting steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
-    const State Nx = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sx, Sn, un,
-                                                          [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, &pr RST_ARG);
-    J += knot_cost_q<M>(P, QW, i, b, q, Sn, un, false);
-    if constexpr (MS) {  // new defect Log(x^_{i+1}^-1 f_q(x^_i,u^_i)), f_xi - xi^_{i+1}
-      State Fn;
-      if constexpr (LINEAR) Fn = dyn_f_k<M, Consts, PK>(DK, C, Sn, un);
-      else Fn = pr.Fn;
-      V3 dw, dv;
-      se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
-      V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
-      d2 += dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
-    }
-    if (writer) {
-      __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB);
-#pragma unroll
-      for (int a = 0; a < M; a++) bst(rSU, vb, a * sB, un[a]);
-      store_state_b(mkbuf(sx + stStride * (i + 1), 13 * sB), vb, sB, Nx);
-    }
-    Sn = Nx;
-  }
-  double uz[M];
-#pragma unroll
-  for (int a = 0; a < M; a++) uz[a] = 0;
-  J += knot_cost_q<M>(P, quadw_load<M>(C, q, true), N, b, q, Sn, uz, true);
-  J = quad_sum(J);
-  if (writer) {
-    P.Jtrial[(size_t)b * 20 + ai] = J;
-    P.dtrial[(size_t)b * 20 + ai] = sqrt(d2);
-  }
-}
-
 // ---- line-search stages, round 3 form -----------------------------------------------------------------------------
 // A stage is three launches: (1) k_rollout_ls -- the closed-loop rollouts alone, the quad form of K3 (roll_step with
 // STORE), one quad per (undecided trajectory, alpha), the undecided trajectories taken from a compacted list so that a
 // wide stage of a few stragglers is a few waves and not a sweep over the batch; (2) k_ls_eval -- stage costs and (MS)
 // squared defects of the stored candidates, one thread per (trajectory, knot, alpha): none of it depends on the
-// rollout chain, on which k_rollout_eval carried it (a second Log, a cost with its own Log, per knot: stage 1 took
+// rollout chain, on which the round-2 kernel (k_rollout_eval, retired) carried it (a second Log, a cost with its own Log, per knot: stage 1 took
 // 0.68 ms SS / 1.10 ms MS against 0.33 ms for the bare rollout); (3) k_ls_sum -- the sums in knot order, the order of
 // _trajectory_cost / _compute_defect_norm (traopt_controller.py:2742-2754, :2790-2821).
-#ifdef TOLG_LS_OCC2
-#define TOLG_LS_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define TOLG_LS_ATTR
-#endif
 template <int M, bool MS, bool LINEAR, int PK>
-__global__ __launch_bounds__(64) TOLG_LS_ATTR void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
+__global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
   const Consts& C = *P.c;  // generic pointer (note at DConsts)
   const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   const int quad = t >> 2, q = t & 3;
@@ -3653,12 +3524,7 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
 // One stage of the speculative line search: alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.
 // stage = 0, 1, 2 ...: stage 0 takes the undecided trajectories from the flags (all active ones), stage s > 0 from the
 // list select s - 1 compacted (lists alternate: select s fills list s & 1 while this stage's kernels read the other).
-// A one-alpha stage writes its candidate in place (no slot, no copy).  TOLG_LS_FUSED_EVAL (environment, read once):
-// the round-2 form, cost and defect on the rollout chain (k_rollout_eval / k_rollout_eval_t) -- for A/B timing.
-static bool ls_fused_eval() {
-  static const bool v = [] { const char* e = getenv("TOLG_LS_FUSED_EVAL"); return e && e[0] == '1'; }();
-  return v;
-}
+// A one-alpha stage writes its candidate in place (no slot, no copy).
 template <int M, bool MS>
 static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int stage, int a0, int n, int linear,
                         hipEvent_t before_select = nullptr) {
@@ -3666,24 +3532,7 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   if (n > NSLOT) return TOLG_E_ARG;
   const bool pend = M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D;
   const int list_in = stage == 0 ? -1 : (stage - 1) & 1, list_out = stage & 1;
-  if (ls_fused_eval()) {
-    Timed t(h, st, 1);
-    if (!direct) {
-      dim3 grid((P.Bp + 63) / 64, n), blk(64);  // one thread per (trajectory, alpha)
-      if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n, -2);
-      else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n, -2);
-    } else {
-      dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per trajectory
-      if (pend) {
-        if (linear) hipLaunchKernelGGL((k_rollout_eval<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct);
-        else hipLaunchKernelGGL((k_rollout_eval<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct);
-      } else {
-        if (linear) hipLaunchKernelGGL((k_rollout_eval<M, MS, true, 0>), grid, blk, 0, st, P, a0, n, direct);
-        else hipLaunchKernelGGL((k_rollout_eval<M, MS, false, 0>), grid, blk, 0, st, P, a0, n, direct);
-      }
-    }
-    LAUNCH_CHECK();
-  } else {
+  {
     Timed t(h, st, 1);
     if (!direct) {  // the thread form of a wide stage: runs when the list is long (ls_quad_form), leaves at once otherwise
       dim3 grid((P.Bp + 63) / 64, n), blk(64);
@@ -3716,7 +3565,7 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   LAUNCH_CHECK();
   if (!direct) {
     size_t nn = (size_t)(P.N + 1) * P.Bp;
-    hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, ls_fused_eval() ? -1 : list_in, n);
+    hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, list_in, n);
     LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, list_out ^ 1);
@@ -3765,10 +3614,10 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
         hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       LAUNCH_CHECK();
       if (hipEventRecord(h->side_ev[1], h->side) != hipSuccess) return TOLG_E_LAUNCH;
-      // staged: the first try alone (the common accept: one quad rollout, written in place), then 4 + 8 (+ 7) alphas
-      // of the trajectories still undecided -- iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20
-      // (:2472).  Measured: the merit search of this workload rarely accepts the first alpha, and one stage of 19
-      // took 5.2 ms against 3 x 0.7.
+      // staged: the first try alone (one quad rollout, written in place), then 4 + 8 (+ 7) alphas of the trajectories
+      // still undecided -- iLQR_Tracking_SO3_MS searches 13 alphas (:1160), the SE3 one 20 (:2472).  On the benchmark
+      // workload ~75 % of the active trajectories accept the first alpha, nearly all the others the second
+      // (tools/ls_alpha_histogram.py); one stage of 19 took 5.2 ms against 3 x 0.7 in round 2.
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear))) return rc;
