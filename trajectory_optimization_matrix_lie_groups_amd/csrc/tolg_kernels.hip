@@ -2853,6 +2853,8 @@ __global__ void k_ls_select(Params P, int a0, int nslots, int out) {
     }
     if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = s; return; }
   }
+  // (an ordered compaction -- one workgroup, a scan -- instead of the counter was measured: no gain, 405 -> 395 it/s;
+  // waves take their turns at the counter nearly in order as it is)
   const int pos = atomicAdd(&P.ls_count[out], 1);
   P.ls_list[(size_t)out * P.Bp + pos] = b;
   P.ls_pos[(size_t)out * P.Bp + b] = pos;
@@ -3644,6 +3646,9 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
     if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
+    // (1 + 4 + 8 like the merit search was measured: 405 -> 339 it/s on iterations 3..23 of the benchmark solve, whose
+    // searches end at the 6th to 10th step size -- tools/ls_alpha_histogram.py; it would pay from iteration ~45 on, where
+    // the median accepted step size is the second one)
     if ((rc = run_ls_stage<M, false>(h, P, st, 1, 1, NALPHA_SS - 1, opt->rollout_linear))) return rc;
     hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
