@@ -145,3 +145,28 @@ def test_large_rotation_deviation_is_handed_back():
                  "ring form + hand-back vs statement form")
     same = _same_search(ia, Ja, None, o["iters"], o["J_hist"], None, 1e-8, "ring form + hand-back vs oracle")
     assert _rel(ua[same], o["us"][same]) < 1e-6
+
+
+@pytest.mark.parametrize("mode,line_search", [("ss", False), ("ms", True)])
+def test_wide_stage_forms_agree_at_the_metric_size(mode, line_search):
+    """A wide line-search stage runs as quad rollouts over the compacted list of undecided trajectories while that list is
+    short, as one thread per (trajectory, alpha) when it is long (ls_quad_form, decided on the device).  Only a large
+    batch reaches the second form: the same 12 trajectories solved inside the 4096 x 200 batch of the metric and in a
+    batch of their own (short lists, the form every oracle comparison of the suite exercises) must agree -- and in the
+    large batch the list must indeed have been long (SS: a third of the trajectories backtrack in the early iterations)."""
+    B, N, K = 4096, 200, 5
+    prob, x0_q, x0_xi, us0 = workloads.se3_tracking(B, N=N)
+    pick = np.array([0, 1, 2, 3, 500, 501, 1023, 2048, 2049, 3000, 4094, 4095])
+    big = BatchedTrackingILQR(prob, B)
+    rb = big.fit_batch(x0_q, x0_xi, us0, mode=mode, n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0, line_search=line_search)
+    torch.cuda.synchronize()
+    Ab, Jb, ib = rb.alpha_hist.cpu().numpy(), rb.J_hist.cpu().numpy(), rb.iters.cpu().numpy()
+    small = BatchedTrackingILQR(prob, len(pick))
+    rs = small.fit_batch(x0_q[pick], x0_xi[pick], us0[pick], mode=mode, n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
+                         line_search=line_search)
+    torch.cuda.synchronize()
+    _same_search(ib[pick], Jb[pick], Ab[pick], rs.iters.cpu().numpy(), rs.J_hist.cpu().numpy(), rs.alpha_hist.cpu().numpy(),
+                 1e-9, "large batch vs batch of twelve")
+    if mode == "ss":  # the thread form's turn needs more than 20 000 / 12 undecided trajectories in some iteration
+        backtracked = ((Ab[:, :K] < 1.0) & (np.arange(K)[None, :] < ib[:, None])).sum(axis=0)
+        assert backtracked.max() > 20000 // 12, backtracked
