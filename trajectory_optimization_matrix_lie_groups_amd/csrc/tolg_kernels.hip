@@ -2580,7 +2580,10 @@ __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nsl
 // _trajectory_cost / _compute_defect_norm (traopt_controller.py:2742-2754, :2790-2821).
 template <int M, bool MS, bool LINEAR, int PK>
 __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
-  const Consts& C = *P.c;  // generic pointer (note at DConsts)
+  // constants as in K3 (k_rollout): the address-space-4 view for the nonlinear step, the generic pointer for the linear
+  // one (fx_apply reads F_u's constants in the knot loop: note at DConsts)
+  typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
+  const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   const int quad = t >> 2, q = t & 3;
   if (slot >= nslots) return;
@@ -2614,62 +2617,38 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
   double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
   State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
   if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, Sn);
-  const DynK DK = dynk_load(C);
-  State So = roll_load_state(P, 0, vb, sB);
+  const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
 #ifdef TOLG_STAMPS
   RStamps ST;
   for (int k = 0; k < 8; k++) ST.acc[k] = 0;
   ST.t = __builtin_amdgcn_s_memtime();
 #endif
   double un[M];
-  for (int i = 0; i < N; i++) {
-    State Sx = So;  // nominal state of knot i; knot i + 1 is requested before the step needs it
-    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
-    __builtin_amdgcn_sched_barrier(0);
-    // single shooting steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
-    Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sx, Sn, un,
-                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+  auto store = [&](int i) {  // u^_i and x^_{i+1}, at the candidate's place (vs)
     if (writer) {
       __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB);
 #pragma unroll
       for (int a = 0; a < M; a++) bst(rSU, vs, a * sB, un[a]);
       store_state_b(mkbuf(sx + stStride * (i + 1), 13 * sB), vs, sB, Sn);
     }
-  }
-}
-// the first try of the MS merit search, alpha = 1: the factors of :2713-2716 are the identity (note at the record
-// layout), the step is x^+ = f(x^, u^) -- K3's ALPHA1 form, written straight into the candidate arrays
-template <int M, int PK>
-__global__ __launch_bounds__(64) void k_rollout_ls1(Params P) {
-  const Consts& C = *P.c;
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  int b = t >> 2;
-  const int q = t & 3;
-  const bool live = b < P.Bp;
-  if (!live) b = P.Bp - 1;
-  if (!P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
-  const bool writer = live && q == 0;
-  const int N = P.N;
-  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
-  State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
-  if (writer) store_state_b(mkbuf(P.cand, 13 * sB), vb, sB, Sn);
-  const DynK DK = dynk_load(C);
-  State So = roll_load_state(P, 0, vb, sB);
-#ifdef TOLG_STAMPS
-  RStamps ST;
-  for (int k = 0; k < 8; k++) ST.acc[k] = 0;
-  ST.t = __builtin_amdgcn_s_memtime();
-#endif
-  double un[M];
-  for (int i = 0; i < N; i++) {
-    State Sx = So;
-    if (i + 1 < N) So = roll_load_state(P, i + 1, vb, sB);
+  };
+  // K3's loop: two steps per trip, the nominal state fetched two knots ahead into ping-pong registers.  Single shooting
+  // steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
+  State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+  for (int i = 0; i < N; i += 2) {
+    if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
     __builtin_amdgcn_sched_barrier(0);
-    Sn = roll_step<M, false, true, PK, true>(P, C, DK, i, b, q, writer, vb, sB, 1.0, Sx, Sn, un,
-                                             [&](RollIn<M>& R) { roll_load<M, true>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+    Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un,
+                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+    store(i);
+    if (i + 1 >= N) break;
+    if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
+    __builtin_amdgcn_sched_barrier(0);
+    Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un,
+                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i + 1, b, q, vb, sB, R); }, nullptr RST_ARG);
+    store(i + 1);
   }
 }
-
 // stage cost l(x^_i, u^_i) (traopt_cost.py:675-738) and, MS, the squared defect
 // |Log(x^_{i+1}^-1 f_q(x^_i, u^_i))|^2 + |f_xi - xi^_{i+1}|^2 (:2790-2812) of every stored candidate of the stage
 template <int M, bool MS>
@@ -3534,6 +3513,14 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   if (n > NSLOT) return TOLG_E_ARG;
   const bool pend = M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D;
   const int list_in = stage == 0 ? -1 : (stage - 1) & 1, list_out = stage & 1;
+  // the first try, alpha = 1: x^+ = f(x^, u^) for single shooting (:2073-2080) and for the merit search alike (the
+  // factors of :2713-2716 are the identity: note at the record layout) -- K3 itself, written straight into the candidate
+  // arrays (every active trajectory is undecided at this point)
+  const bool k3 = direct && a0 == 0 && !linear;
+  if (k3) {
+    int rc = run_rollout_ms<M>(h, P, st, 1.0, 0, MS ? 1 : 0);
+    if (rc) return rc;
+  }
   {
     Timed t(h, st, 1);
     if (!direct) {  // the thread form of a wide stage: runs when the list is long (ls_quad_form), leaves at once otherwise
@@ -3544,9 +3531,7 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
     }
     {
       dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per (trajectory, alpha)
-      if (MS && direct && a0 == 0 && !linear) {
-        if (pend) hipLaunchKernelGGL((k_rollout_ls1<6, 1>), grid, blk, 0, st, P);
-        else hipLaunchKernelGGL((k_rollout_ls1<M, 0>), grid, blk, 0, st, P);
+      if (k3) {
       } else if (pend) {
         if (linear) hipLaunchKernelGGL((k_rollout_ls<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
         else hipLaunchKernelGGL((k_rollout_ls<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
