@@ -7,7 +7,7 @@ python3 - <<'PY'
 import csv
 for m in ("ss","merit"):
     rows=list(csv.DictReader(open(f"gpurun_out/r03b_stats_{m}/run_kernel_trace.csv")))
-    ev=[r for r in rows if "k_rollout_eval" in r["Kernel_Name"] or "k_expected" in r["Kernel_Name"]]
+    ev=[r for r in rows if "k_rollout" in r["Kernel_Name"] or "k_ls_" in r["Kernel_Name"] or "k_expected" in r["Kernel_Name"]]
     ev.sort(key=lambda r:int(r["Start_Timestamp"]))
     out=[(r["Kernel_Name"].split("::")[1][:14], r["Grid_Size_Y"], round((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)) for r in ev]
     print(m, out[20:44])
