@@ -170,3 +170,38 @@ def test_wide_stage_forms_agree_at_the_metric_size(mode, line_search):
     if mode == "ss":  # the thread form's turn needs more than 20 000 / 12 undecided trajectories in some iteration
         backtracked = ((Ab[:, :K] < 1.0) & (np.arange(K)[None, :] < ib[:, None])).sum(axis=0)
         assert backtracked.max() > 20000 // 12, backtracked
+
+
+@pytest.mark.parametrize("kind", ["se3", "drone"])
+def test_al_terms_in_both_forms_and_in_the_staged_search(kind):
+    """Augmented-Lagrangian solves carry one more record field (the l_uu diagonal) and a cost with multiplier terms: the
+    ring kernel reads the first, k_ls_eval evaluates the second.  Kernel against kernel on a random trajectory, then a
+    merit search with the ring form against one with the statement form (and single shooting, which has only the
+    staged evaluation to differ in, against itself through both schedules)."""
+    B, N, K = 6, 45, 5
+    prob, x0_q, x0_xi, us0 = _problem(kind, B, N)
+    m = prob.m
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(2)
+    lam = torch.tensor(rng.uniform(0.0, 0.5, size=(B, N, 2 * m)), dtype=torch.float64, device=dev)
+    imu = torch.tensor(rng.uniform(0.5, 3.0, size=(B, N, 2 * m)), dtype=torch.float64, device=dev)
+    solver = BatchedTrackingILQR(prob, B)
+    solver.set_al(-0.4 * np.ones(m), 0.4 * np.ones(m), lam, imu)
+    xs_q, xs_xi, us = _random_traj(prob, B, seed=9, spread=0.05)
+    solver.linearize_backward(xs_q, xs_xi, us, ms=True)
+    es, _ = solver.expected_change(B, "statement")
+    er, flag = solver.expected_change(B, "ring")
+    torch.cuda.synchronize()
+    es, er, flag = es.cpu().numpy(), er.cpu().numpy(), flag.cpu().numpy()
+    assert (flag == 0).all()
+    assert (np.abs(er - es) / np.abs(es).max(axis=1, keepdims=True)).max() < 1e-11
+    res = {}
+    for mode, ls in (("ms", True), ("ss", False)):
+        for sched in ("auto", "split"):
+            r = solver.fit_batch(x0_q, x0_xi, us0, mode=mode, n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
+                                 line_search=ls, schedule=sched)
+            torch.cuda.synchronize()
+            res[mode, sched] = (r.iters.cpu().numpy().copy(), r.J_hist.cpu().numpy().copy(), r.alpha_hist.cpu().numpy().copy())
+        a, s_ = res[mode, "auto"], res[mode, "split"]
+        _same_search(a[0], a[1], a[2], s_[0], s_[1], s_[2], 1e-10, "AL %s: auto vs split schedule" % mode)
+    solver.set_al(None)
