@@ -72,8 +72,8 @@ def _args():
     """Angles on both sides of every threshold of tolg_lie.h, log-spaced fill, each with a few axes; shuffled so that a
     wavefront of 64 consecutive argument sets mixes small / long / out-of-domain lanes."""
     rng = np.random.default_rng(7)
-    edges = [1e-10, 0.01, 0.04, 0.26, 1.0]                       # th2 thresholds: eps, ljinv_small, exp/coef_small, ljinv_dom, dom
-    edges += [(2 * np.arcsin(np.sqrt(y))) ** 2 for y in (1e-3, 0.0625)]  # the Log's y thresholds as angles
+    edges = [1e-10, 0.01, 0.04, 1.0, 1.21]                       # th2 thresholds: eps, ljinv_small, exp/coef_small, exp_dom, coef/ljinv_dom
+    edges += [(2 * np.arcsin(np.sqrt(y))) ** 2 for y in (1e-3, 0.0625, 0.25)]  # the Log's y thresholds as angles (+ the round-2 one)
     th2 = []
     for e in edges:
         th2 += [e * (1 - 1e-6), e * (1 + 1e-6), e * 0.9, e * 1.1]

@@ -201,7 +201,7 @@ TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
 // division; truncation errors are below 1e-17 relative, i.e. they agree with the closed forms above to rounding.
 // Shape of every function: the series runs unconditionally as straight-line code, manif's small-angle values
 // (th2 <= 1e-10) are selected in, and the lanes outside the domain (a rotation of more than 1 rad per step, a
-// deviation of more than ~29 degrees) are redone with the closed form behind a wave-uniform branch that a
+// deviation of more than 60 degrees) are redone with the closed form behind a wave-uniform branch that a
 // tracking solve never takes after its first iterations.  The series have two lengths: where the argument is
 // `small` (per-step rotation below 0.2 rad, deviation below 0.06 rad -- the steady state of a tracking solve) the
 // terms past the short length are below 1e-17 of the sum, and a wave whose lanes are all small skips them.
@@ -220,15 +220,15 @@ TOLG_DEV SeriesGate series_gate(bool small, bool dom) {
 }
 // Per-lane predicates of the four argument kinds.  A gate built from log_small / log_dom of y = |q_v|^2 also
 // covers the evaluations at the resulting angle th2 = (2 asin sqrt y)^2: y < 1e-3 gives th2 < 4.002e-3 (inside
-// coef_small and ljinv_small), y < 1/16 gives th2 < 0.2554 (inside coef_dom and ljinv_dom).  horner2 trusts the
+// coef_small and ljinv_small), y < 1/4 gives th2 < 1.0967 (inside coef_dom and ljinv_dom).  horner2 trusts the
 // gate (any_long false = every lane small for EVERY series evaluated under it), so the thresholds are tied together
 // at compile time: callers share one gate between Exp and coefficient series in both directions (roll_step: an
 // exp_small gate over the (th - sin th)/th^3 series; lin_knot: a coef_small gate over so3_exp_fast), and between
 // Log and the series evaluated at the Log's angle.
 constexpr double kExpSmall = 0.04, kExpDomHi = 1.0;        // 5 / 6 / 6 terms reach 1e-17
-constexpr double kLogSmallY = 1e-3, kLogDomY = 0.0625;     // 6 / 5 terms
-constexpr double kCoefSmall = 0.04, kCoefDom = 1.0;        // 6 terms of each
-constexpr double kLjinvSmall = 0.01, kLjinvDom = 0.26;     // 5 terms
+constexpr double kLogSmallY = 1e-3, kLogDomY = 0.25;       // 6 / 5 terms; long tier: a deviation of up to 60 degrees
+constexpr double kCoefSmall = 0.04, kCoefDom = 1.21;       // 6 terms of each (long tier: 10 / 9, below 1e-17 up to 1.21)
+constexpr double kLjinvSmall = 0.01, kLjinvDom = 1.21;     // 5 terms (long tier: 12)
 // upper bound of (2 asin x)^2: asin x = x + x^3/6 + 3x^5/40 + 15x^7/336 + ..., coefficients decreasing, so the
 // tail after the x^7 term is below (35/1152) x^9 / (1 - x^2)
 constexpr double angle2_ub(double x) {
@@ -236,7 +236,7 @@ constexpr double angle2_ub(double x) {
   const double a = x * (1.0 + x2 * (1.0 / 6 + x2 * (3.0 / 40 + x2 * (15.0 / 336)))) + (35.0 / 1152) * x2 * x2 * x2 * x2 * x / (1.0 - x2);
   return 4.0 * a * a;
 }
-constexpr double kLogSmallX = 0.0316228, kLogDomX = 0.25;  // >= sqrt of the y thresholds
+constexpr double kLogSmallX = 0.0316228, kLogDomX = 0.5;   // >= sqrt of the y thresholds
 static_assert(kLogSmallX * kLogSmallX >= kLogSmallY && kLogDomX * kLogDomX >= kLogDomY, "x bounds of the Log thresholds");
 static_assert(kExpSmall == kCoefSmall, "one gate serves Exp and coefficient series in both directions");
 static_assert(kExpDomHi <= kCoefDom, "an exp_dom gate covers so3_coef_fast at the same angle");
@@ -326,14 +326,21 @@ TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v, SeriesGate g) {
   const Q4 q = X.q;
   const double y = quat_vec2(q);
   const bool tiny = !(y > TOLG_EPS), sm = log_small(y);
-  // asin(sqrt y)/sqrt y and 1/t^2 - cot(t/2)/(2t) = sum |B_{2k+2}|/(2k+2)! t^2k
-  const double A[14] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144, 0.030381944444444444,
-                        0.022372159090909092, 0.017352764423076924, 0.01396484375, 0.011551800896139705,
-                        0.009761609529194078, 0.008390335809616815, 0.0073125258735988454, 0.006447210311889649,
-                        0.005740037670841924};
-  const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
-                       2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
-                       8.586062056277845e-15};
+  // asin(sqrt y)/sqrt y: the first six Taylor coefficients (the short tier: y < 1e-3), then y^6 times the degree-10
+  // interpolant of the remainder at the Chebyshev nodes of [0, 1/4] -- 5.4e-19 relative on the whole interval with 17
+  // coefficients, where the 14 Taylor terms of rounds 2-3 reached 1e-17 on y < 1/16 only: the singularity at y = 1 is
+  // as far away either way, but the interpolant spends its degrees of freedom on the interval, not on a disc
+  // (tools/gen_log_series.py, 60-digit arithmetic).  A deviation of up to 60 degrees (29 before) stays on the series:
+  // the rollouts and linearisations of a solve's first iterations, where the closed forms cost a stage rollout half
+  // its time again (0.41 against 0.28 ms).
+  // 1/t^2 - cot(t/2)/(2t) = sum |B_{2k+2}|/(2k+2)! t^2k: 12 terms reach 4e-19 on t^2 <= 1.21.
+  const double A[17] = {1.0, 0.16666666666666667, 0.075, 0.044642857142857143, 0.030381944444444444,
+                        0.022372159090909091, 0.017352764423078705, 0.013964843748277154, 0.011551801170464363,
+                        0.009761592565719998, 0.0083908710662676442, 0.0073027366952445512, 0.0065578263896588765,
+                        0.0049481126918453019, 0.0087132163323646033, -0.0048408125598408092, 0.01700421839934941};
+  const double L[12] = {0.083333333333333333, 0.0013888888888888889, 3.3068783068783069e-5, 8.2671957671957672e-7,
+                        2.0876756987868099e-8, 5.2841901386874932e-10, 1.3382536530684679e-11, 3.3896802963225829e-13,
+                        8.5860620562778446e-15, 2.1748686985580619e-16, 5.5090028283602295e-18, 1.3954464685812523e-19};
   double c = 2.0 * horner2<6>(A, y, sm, g.any_long);  // angle / |q_v|
   const double t2 = c * c * y;                        // angle^2 (< 4.1e-3 when sm)
   double cl = horner2<5>(L, t2, sm, g.any_long);
@@ -351,7 +358,7 @@ TOLG_DEV void se3_log_fast(Pose X, V3& w, V3& v) {
   const double y = quat_vec2(X.q);
   se3_log_fast(X, w, v, series_gate(log_small(y), log_dom(y)));
 }
-// Coefficients of V(w) and of the SE(3) Q block as series in th^2 (th^2 < 1: one time step of rotation, or a
+// Coefficients of V(w) and of the SE(3) Q block as series in th^2 (th^2 < 1.21: one time step of rotation, or a
 // tracking error below one radian; otherwise the closed forms).  (1 - cos t)/t^2 = sum (-1)^k t^2k/(2k+2)!,
 // (t - sin t)/t^3 = sum (-1)^k t^2k/(2k+3)!, (t^2 + 2 cos t - 2)/(2 t^4) = sum (-1)^k t^2k/(2k+4)!,
 // (2t - 3 sin t + t cos t)/(2 t^5) = sum (-1)^k (k+1) t^2k/(2k+5)!.  No sqrt / sincos / division, and none of the
@@ -393,9 +400,9 @@ TOLG_DEV SO3Coef so3_coef_fast(double th2, bool want_q) {
 }
 // coefficient of W^2 in V(w)^-1 (ljacinv_coef) as the series of se3_log_fast
 TOLG_DEV double ljacinv_coef_fast(double th2, SeriesGate g) {
-  const double L[9] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05, 8.267195767195768e-07,
-                       2.08767569878681e-08, 5.284190138687493e-10, 1.3382536530684679e-11, 3.3896802963225827e-13,
-                       8.586062056277845e-15};
+  const double L[12] = {0.083333333333333333, 0.0013888888888888889, 3.3068783068783069e-5, 8.2671957671957672e-7,
+                        2.0876756987868099e-8, 5.2841901386874932e-10, 1.3382536530684679e-11, 3.3896802963225829e-13,
+                        8.5860620562778446e-15, 2.1748686985580619e-16, 5.5090028283602295e-18, 1.3954464685812523e-19};
   double r = horner2<5>(L, th2, ljinv_small(th2), g.any_long);
   if (!(th2 > TOLG_EPS)) r = 0.0;
   if (__builtin_expect(g.any_fb, 0)) {
