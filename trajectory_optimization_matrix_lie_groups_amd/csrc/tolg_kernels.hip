@@ -1637,8 +1637,8 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
 // and c_i is zero up to rounding, so the sequential chain holds one Log, one Exp and the K dx product
 // per knot; the alpha < 1 line-search steps build the factors from the stored defect.
 // ------------------------------------------------------------------------------------------------
-template <int M>
-TOLG_DEV void fx_apply(const Params& P, const Consts& C, int i, int b, const double (&e)[12],
+template <int M, class CT>
+TOLG_DEV void fx_apply(const Params& P, const CT& C, int i, int b, const double (&e)[12],
                        const double (&du)[M], double (&lin)[12]) {
   // lin = F_x e + F_u du from the compact record (rollout == 'linear')
   double Ri[9], TRi[9], Jr[9], Qr[9];
@@ -1832,7 +1832,11 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   } else {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
     double lin[12], d[12];
+#ifdef TOLG_AS4_LINEAR  // (experiment: the round-2 failure -- F_u's constants through address space 4 inside a knot loop)
+    fx_apply<M>(P, C, i, b, e, du, lin);
+#else
     fx_apply<M>(P, *P.c, i, b, e, du, lin);
+#endif
 #pragma unroll
     for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), FOFF(REC_D + a));
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
@@ -1907,7 +1911,11 @@ template <int M, bool LINEAR, bool ALPHA1, int PK = 0>
 __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
+#ifdef TOLG_AS4_LINEAR
+  typedef DConsts CT;
+#else
   typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
+#endif
   const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int b = t >> 2;
@@ -2582,7 +2590,11 @@ template <int M, bool MS, bool LINEAR, int PK>
 __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
   // constants as in K3 (k_rollout): the address-space-4 view for the nonlinear step, the generic pointer for the linear
   // one (fx_apply reads F_u's constants in the knot loop: note at DConsts)
+#ifdef TOLG_AS4_LINEAR
+  typedef DConsts CT;
+#else
   typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
+#endif
   const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   const int quad = t >> 2, q = t & 3;
