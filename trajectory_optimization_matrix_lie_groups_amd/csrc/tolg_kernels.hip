@@ -3235,6 +3235,22 @@ extern "C" size_t tolg_workspace_bytes(const tolg_problem* prob, int32_t max_bat
 
 extern "C" const char* tolg_version(void) { return "tolg-hip 0.3 (gfx950)"; }
 
+// LDS is not cleared between launches: a kernel that reads LDS it has not written usually meets what the previous
+// launch of the same kernel left at the same offsets -- the right values -- and passes its tests (k_expected_change did,
+// for one commit: DESIGN.md section 4).  k_poison_lds fills the LDS of every CU with NaNs; TOLG_POISON_LDS=1 in the
+// environment (read once) puts one behind EVERY launch of the library, on the null stream (a debugging mode: it
+// serialises the streams), so that such a read shows anywhere in the test suite; the unit-parity entry point
+// tolg_expected_change always runs one first.
+__global__ __launch_bounds__(256) void k_poison_lds() {
+  __shared__ double junk[8192];
+  for (int k = threadIdx.x; k < 8192; k += 256) junk[k] = __builtin_nan("");
+  __syncthreads();
+  if (junk[(threadIdx.x * 33) & 8191] == 0.0) __builtin_trap();  // keeps the stores alive; never true
+}
+static bool poison_lds_mode() {
+  static const bool v = [] { const char* e = getenv("TOLG_POISON_LDS"); return e && e[0] == '1'; }();
+  return v;
+}
 #define LAUNCH_CHECK()                                         \
   do {                                                         \
     hipError_t e_ = hipGetLastError();                         \
@@ -3242,6 +3258,7 @@ extern "C" const char* tolg_version(void) { return "tolg-hip 0.3 (gfx950)"; }
       fprintf(stderr, "tolg: launch failed at %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
       return TOLG_E_LAUNCH;                                    \
     }                                                          \
+    if (poison_lds_mode()) hipLaunchKernelGGL(k_poison_lds, dim3(2048), dim3(256), 0, 0); \
   } while (0)
 
 extern "C" int tolg_create(const tolg_problem* prob, const double* d_q_ref, const double* d_xi_ref,
@@ -3874,15 +3891,6 @@ __global__ void k_clear_ecc(Params P) {
   if (b >= P.Bp) return;
   P.ecc[2 * b] = __builtin_nan(""); P.ecc[2 * b + 1] = __builtin_nan(""); P.ec_redo[b] = 0;
   P.dweight[2 * b] = 10.0; P.dweight[2 * b + 1] = 10.0;
-}
-// LDS is not cleared between launches: a kernel that reads LDS it has not written usually meets what the previous
-// launch of the same kernel left at the same offsets -- the right values -- and passes its tests.  The unit-parity entry
-// point below fills the LDS of every CU with NaNs first, so that such a read shows.
-__global__ __launch_bounds__(256) void k_poison_lds() {
-  __shared__ double junk[8192];
-  for (int k = threadIdx.x; k < 8192; k += 256) junk[k] = __builtin_nan("");
-  __syncthreads();
-  if (junk[(threadIdx.x * 33) & 8191] == 0.0) __builtin_trap();  // keeps the stores alive; never true
 }
 extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, double* d_ecc, int32_t* d_flag, void* stream) {
   // works on what tolg_linearize_backward left in the workspace (trajectory, records, gains): not during a solve
