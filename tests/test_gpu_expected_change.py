@@ -43,7 +43,8 @@ def _random_traj(prob, B, seed, spread):
     return xs_q, xs_xi, us
 
 
-@pytest.mark.parametrize("kind,B,N", [("se3", 7, 33), ("se3", 64, 200), ("drone", 5, 60), ("drone", 12, 150), ("so3", 4, 40)])
+@pytest.mark.parametrize("kind,B,N", [("se3", 7, 33), ("se3", 64, 200), ("drone", 5, 60), ("drone", 12, 150), ("so3", 4, 40),
+                                      ("se3", 1, 1), ("se3", 3, 2), ("drone", 2, 3), ("se3", 5, 5), ("se3", 17, 6)])  # horizons shorter than the ring
 @pytest.mark.parametrize("spread", [0.02, 0.15])
 def test_ring_kernel_matches_statement_kernel_on_random_trajectories(kind, B, N, spread):
     """The two kernels on the same records and gains (open trajectories with defects of size `spread`): first- and
