@@ -54,6 +54,40 @@ def test_sgpr_written_by_valu_then_read_by_vector_memory(between, n_findings):
     assert _dpp_lint.lint(t) == []
 
 
+@pytest.mark.parametrize("seq, n_findings", [
+    # 3: transcendental result -> non-transcendental VALU
+    (["v_rcp_f64_e32 v[4:5], v[0:1]", "v_fma_f64 v[6:7], v[4:5], v[2:3], v[2:3]"], 1),
+    (["v_rcp_f64_e32 v[4:5], v[0:1]", "s_nop 0", "v_fma_f64 v[6:7], v[4:5], v[2:3], v[2:3]"], 0),
+    (["v_rcp_f64_e32 v[4:5], v[0:1]", "v_rsq_f64_e32 v[6:7], v[4:5]"], 0),
+    # 4: SGPR / VCC written by a VALU instruction -> VALU read
+    (["v_cmp_lt_f64_e64 s[4:5], v[0:1], v[2:3]", "v_cndmask_b32_e64 v7, v1, v2, s[4:5]"], 1),
+    (["v_cmp_lt_f64_e64 s[4:5], v[0:1], v[2:3]", "v_mov_b32_e32 v9, v8", "v_cndmask_b32_e64 v7, v1, v2, s[4:5]"], 1),
+    (["v_cmp_lt_f64_e64 s[4:5], v[0:1], v[2:3]", "s_nop 1", "v_cndmask_b32_e64 v7, v1, v2, s[4:5]"], 0),
+    (["v_add_co_u32_e32 v1, vcc, v2, v3", "v_addc_co_u32_e32 v4, vcc, v5, v6, vcc"], 1),
+    (["v_add_co_u32_e32 v1, vcc, v2, v3", "v_mov_b32_e32 v9, v8", "s_nop 0", "v_addc_co_u32_e32 v4, vcc, v5, v6, vcc"], 0),
+    (["v_readfirstlane_b32 s7, v3", "v_mul_f64 v[4:5], s[6:7], v[0:1]"], 1),
+    (["s_mov_b32 s7, s9", "v_mul_f64 v[4:5], s[6:7], v[0:1]"], 0),
+    # 5: VGPR written by a VALU instruction -> readlane; lane select
+    (["v_add_u32_e32 v3, v1, v2", "v_readfirstlane_b32 s7, v3"], 1),
+    (["v_add_u32_e32 v3, v1, v2", "s_nop 0", "v_readfirstlane_b32 s7, v3"], 0),
+    (["v_readfirstlane_b32 s7, v3", "s_nop 2", "v_readlane_b32 s8, v5, s7"], 1),
+    (["v_readfirstlane_b32 s7, v3", "s_nop 3", "v_readlane_b32 s8, v5, s7"], 0),
+    # 6: EXEC written by v_cmpx -> DPP
+    (["v_cmpx_lt_f64_e32 v[0:1], v[2:3]", "s_nop 3", "v_mov_b32_dpp v4, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"], 1),
+    (["v_cmpx_lt_f64_e32 v[0:1], v[2:3]", "s_nop 4", "v_mov_b32_dpp v4, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"], 0),
+    # 7: M0 -> LDS-DMA
+    (["s_mov_b32 m0, s31", "global_load_lds_dwordx4 v[28:29], off"], 1),
+    (["s_mov_b32 m0, s31", "s_nop 0", "global_load_lds_dwordx4 v[28:29], off"], 0),
+    (["s_mov_b32 m0, s31", "buffer_load_dword v1, s[4:7], 0 offen lds"], 1),
+    (["s_mov_b32 m0, s31", "global_load_dwordx4 v[0:3], v[28:29], off"], 0),
+])
+def test_further_rules_on_synthetic_disassembly(seq, n_findings):
+    t = HEAD
+    for i, ins in enumerate(seq):
+        t += _ins(ins, 8 * i)
+    assert len(_dpp_lint.lint_more(t)) == n_findings, _dpp_lint.lint_more(t)
+
+
 def test_branch_target_in_window_is_reported():
     t = HEAD + _ins("s_cbranch_execz 2 ", 0).replace("//", "// 0 <k+0x10>") + _ins("v_add_f64 v[30:31], v[0:1], v[2:3]", 8) + DPP % 0x10
     assert any("branch target" in f[2] for f in _dpp_lint.lint(t))
@@ -68,3 +102,4 @@ def test_in_tree_library_has_no_dpp_hazard():
     text = _dpp_lint.disassemble(lib)
     assert text.count("_dpp") > 1000  # the blocks are there
     assert _dpp_lint.lint(text) == []
+    assert _dpp_lint.lint_more(text) == []

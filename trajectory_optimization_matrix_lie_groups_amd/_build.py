@@ -74,7 +74,8 @@ def build_extension(force=False, verbose=False, extra_flags=(), lint=True):
     if lint:
         # the hand-written DPP blocks run without hazard nops where the emitted code keeps the distance: check that it does
         from . import _dpp_lint
-        findings = _dpp_lint.lint(_dpp_lint.disassemble(_SO))
+        _isa = _dpp_lint.disassemble(_SO)
+        findings = _dpp_lint.lint(_isa) + _dpp_lint.lint_more(_isa)
         if findings:
             bad = _SO + ".hazard"
             os.replace(_SO, bad)

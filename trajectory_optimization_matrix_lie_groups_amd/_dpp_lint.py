@@ -16,6 +16,16 @@ Second rule, same reason (the LDS-DMA bursts are inline asm with a scalar base a
 an SGPR (v_readfirstlane, v_readlane, a carry-out, a compare) must be five wait states ahead of a vector-memory
 instruction that reads that SGPR.
 
+Rules three to seven (late round 3) are the rest of what LLVM's hazard recogniser pads on gfx940-class parts and cannot
+see through an inline-asm statement -- checked over ALL code, so the compiler's own padding is verified along the way:
+  3. a transcendental result (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) read by a non-transcendental
+     VALU instruction: 1 wait state;
+  4. an SGPR or VCC written by a VALU instruction (compare, carry-out, readlane) read by a VALU instruction: 2;
+  5. a VGPR written by a VALU instruction read by v_readlane / v_readfirstlane / v_writelane: 1; their lane select
+     from a VALU-written SGPR: 4;
+  6. EXEC written by a VALU instruction (v_cmpx) in front of a DPP instruction: 5;
+  7. M0 written by a scalar instruction in front of an LDS-DMA load (`global_load_lds_*`, `buffer_load_* ... lds`): 1.
+
 A branch target inside the window is reported as well (the other predecessor cannot be seen in a linear scan).
 
     python tools/dpp_hazard_lint.py [path/to/libtolg_hip.so]      exit code 1 on a finding
@@ -150,9 +160,83 @@ def lint(text):
     return findings
 
 
+_TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+_DPP_CTRL = ("row_newbcast", "row_shl", "row_shr", "quad_perm", "row_bcast", "row_ror", "row_mirror", "wave_", "row_half_mirror")
+
+
+def _carry_form(op):
+    return "_co_" in op or op.startswith("v_div_scale")
+
+
+def lint_more(text):
+    """Rules 3-7 of the module docstring -> list of (kernel, address, message)."""
+    findings, kernel, prev = [], None, []   # prev: (wait states, opcode, VGPRs written, SGPRs written, exec written, m0 written)
+    for ln in text.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
+        if m:
+            kernel, prev = m.group(2), []
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+        if not m or kernel is None:
+            continue
+        op, args, addr = m.group(1), m.group(2), int(m.group(3), 16)
+        toks = [t.strip() for t in args.split(",")]
+        if _is_valu(op):
+            srcs = ",".join(toks[2:] if _carry_form(op) else toks[1:])
+            vread, sread = _regs(srcs), set(_sregs(srcs))
+            if op.startswith("v_cmp") and not op.startswith("v_cmpx") and toks and toks[0].startswith("v"):
+                vread |= _regs(toks[0])        # e32 compare: the first token is a source
+            if "vcc" in srcs:
+                sread.add("vcc")
+            is_dpp = op.endswith("_dpp") or any(k in args for k in _DPP_CTRL)
+            lane_op = op.startswith(("v_readlane", "v_readfirstlane", "v_writelane"))
+            ws = 0
+            for w_ws, w_op, vw, sw, ew, _m0 in reversed(prev):
+                if ws < 1 and w_op.startswith(_TRANS) and not op.startswith(_TRANS) and (vw & vread):
+                    findings.append((kernel, addr, "%s reads v%s %d wait state(s) after the transcendental %s wrote it (1)"
+                                     % (op, sorted(vw & vread), ws, w_op)))
+                if ws < 2 and (sw & sread):
+                    findings.append((kernel, addr, "%s reads %s %d wait state(s) after the VALU instruction %s wrote it (2)"
+                                     % (op, sorted(map(str, sw & sread)), ws, w_op)))
+                if ws < 1 and lane_op and (vw & vread):
+                    findings.append((kernel, addr, "%s reads v%s %d wait state(s) after %s wrote it (1)" % (op, sorted(vw & vread), ws, w_op)))
+                if ws < 4 and op.startswith(("v_readlane", "v_writelane")) and len(toks) > 2 and (sw & set(_sregs(toks[2]))):
+                    findings.append((kernel, addr, "%s takes its lane select %d wait state(s) after %s wrote it (4)" % (op, ws, w_op)))
+                if ws < 5 and ew and is_dpp:
+                    findings.append((kernel, addr, "DPP %s %d wait state(s) after %s wrote EXEC (5)" % (op, ws, w_op)))
+                ws += w_ws
+                if ws >= 5:
+                    break
+        if _is_vmem(op) and ("_lds_" in op or re.search(r"\blds\b", args)):
+            if prev and prev[-1][5]:
+                findings.append((kernel, addr, "%s directly behind %s (M0 write -> LDS-DMA: 1)" % (op, prev[-1][1])))
+        if op == "s_nop":
+            prev.append(((int(args.split()[0], 0) if args else 0) + 1, op, set(), set(), False, False))
+        else:
+            vw, sw, ew, m0w = set(), set(), False, False
+            if _is_valu(op) and toks:
+                if op.startswith("v_cmpx"):
+                    ew = True
+                elif op.startswith("v_cmp"):
+                    sw = set(_sregs(toks[0])) | ({"vcc"} if (toks[0] == "vcc" or toks[0].startswith("v")) else set())
+                elif op.startswith(("v_readfirstlane", "v_readlane")):
+                    sw = set(_sregs(toks[0]))
+                elif _carry_form(op):
+                    vw = _regs(toks[0])
+                    sw = set(_sregs(toks[1])) | ({"vcc"} if len(toks) > 1 and "vcc" in toks[1] else set())
+                elif not op.startswith("v_accvgpr_write"):
+                    vw = _regs(toks[0])
+            elif op.startswith("s_") and toks and toks[0] == "m0":
+                m0w = True
+            prev.append((1, op, vw, sw, ew, m0w))
+        prev = prev[-12:]
+    return findings
+
+
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtolg_hip.so")
-    f = lint(disassemble(lib))
+    text = disassemble(lib)
+    f = lint(text) + lint_more(text)
     for k, a, msg in f:
         print("%s  %x: %s" % (k, a, msg))
     print("%d finding(s) in %s" % (len(f), lib))
