@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--allow-lib-override", action="store_true",
                     help="accept TOLG_HIP_LIB (another build of the C ABI, A/B timing); refused otherwise")
     ap.add_argument("--deadline", type=float, default=1500.0, help="seconds after which the launcher kills its ranks")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="one rank only: take the multi-rank code path anyway (RCCL process group of size 1, barriers, the MAX "
+                         "all-reduce, the final gather on the device) -- what a one-GPU box can verify of --gpus N")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only (gloo on CPU, no solver): used by the CPU tests")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1,
@@ -332,12 +335,17 @@ def run_rank(args, rank, world):
 
     ident = library_identity(args.allow_lib_override)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1:
+    multi = world > 1 or args.rccl_selftest   # every `if multi` below is the multi-rank path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rccl_selftest and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
 
     N, K, W, R = args.horizon, args.steps, args.warmup, max(1, args.repeats)
@@ -360,7 +368,7 @@ def run_rank(args, rank, world):
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -378,7 +386,7 @@ def run_rank(args, rank, world):
         ms_b, ms_r, ms_l, n_b = solver.kernel_time(reset=True)
         solver.enable_timing(False)
         el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         regions.append(float(el.item()))
         kern.append((ms_b / max(n_b, 1), ms_r / max(n_b, 1), ms_l / max(n_b, 1)))
@@ -404,7 +412,7 @@ def run_rank(args, rank, world):
     active_end = float((res.iters == total).double().mean().item())
     # final gather of costs / controls over RCCL (outside the timed solve, reported separately)
     gather_ms, gather_err = None, None
-    if world > 1:
+    if multi:
         try:
             last = (res.iters.clamp(min=1) - 1).long().reshape(-1, 1)
             Jf = torch.gather(res.J_hist, 1, last).contiguous()
@@ -460,6 +468,8 @@ def run_rank(args, rank, world):
                                          "min_ms_per_step": min(regions) / K * 1e3,
                                          "max_ms_per_step": max(regions) / K * 1e3},
                        "kernel_ms_per_step": {"backward": kb, "rollout": kr, "linearize": kl},
+                       **({"rccl_selftest": "process group of one rank: barrier, all_reduce(MAX), all_gather ran on the device"}
+                          if (args.rccl_selftest and world == 1) else {}),
                        "final_gather_ms": gather_ms, **({"final_gather_error": gather_err} if gather_err else {}),
                        **ident},
             # `frac` is SURVEY §8d's own formula: algorithmic bytes of one batch-iteration over the WHOLE step.
@@ -484,7 +494,7 @@ def run_rank(args, rank, world):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(prob, x0_q, x0_xi, us0, args.cpu_seconds, args.mode, args.line_search)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0
