@@ -62,9 +62,12 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (weak) or in all (strong); default 4096 (se3) / 8192 (drone400)")
     ap.add_argument("--horizon", type=int, default=None, help="default 200 (se3) / 400 (drone400)")
-    ap.add_argument("--workload", choices=["se3", "drone400"], default="se3")
+    ap.add_argument("--workload", choices=["se3", "drone400", "so3", "al1024"], default="se3",
+                    help="se3: the metric's workload; drone400 / so3 / al1024: BASELINE configs 5 / 2 / 4 at their stated sizes "
+                         "(secondary lines; so3 defaults to the SS solver its script uses, al1024 times inner MS iterations with "
+                         "the AL terms of the first outer iteration attached)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default weak (se3) / strong (drone400)")
-    ap.add_argument("--mode", choices=["ms", "ss"], default="ms")
+    ap.add_argument("--mode", choices=["ms", "ss"], default=None, help="default ms (ss for --workload so3)")
     ap.add_argument("--line-search", action="store_true")
     ap.add_argument("--schedule", choices=["auto", "split"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,11 +84,13 @@ def parse_args(argv=None):
                     help="(tests) with --dry-run: this rank exits 3 before the rendezvous")
     a = ap.parse_args(argv)
     if a.batch is None:
-        a.batch = 4096 if a.workload == "se3" else 8192
+        a.batch = {"se3": 4096, "drone400": 8192, "so3": 1, "al1024": 1024}[a.workload]
     if a.horizon is None:
-        a.horizon = 200 if a.workload == "se3" else 400
+        a.horizon = {"se3": 200, "drone400": 400, "so3": 100, "al1024": 200}[a.workload]
     if a.scaling is None:
-        a.scaling = "weak" if a.workload == "se3" else "strong"
+        a.scaling = "strong" if a.workload == "drone400" else "weak"
+    if a.mode is None:
+        a.mode = "ss" if a.workload == "so3" else "ms"
     return a
 
 
@@ -352,7 +357,12 @@ def run_rank(args, rank, world):
     B, B_global = local_and_global_batch(args, rank, world)
     if B < 1:
         raise SystemExit("bench.py: --batch %d leaves rank %d without a trajectory" % (args.batch, rank))
-    make = workloads.se3_tracking if args.workload == "se3" else workloads.drone_tracking
+    # drone400: R = 1e-3 I.  With the R = 1e-5 of benchmark_drone_racing_tracking.py:208 (a 150-knot problem) accept-always MS
+    # diverges on the 400-knot problem for nearly every member -- in the oracle as on the GPU, tests/test_gpu_configs.py --
+    # and a diverged trajectory stops doing work: tools/drone_spread_survival.py, profiles/r03_drone_spread_survival.txt
+    drone = lambda B_, N=400, seed=workloads.SEED: workloads.drone_tracking(B_, N=N, seed=seed, R_scale=1e-3)
+    make = {"se3": workloads.se3_tracking, "drone400": drone, "so3": workloads.so3_tracking,
+            "al1024": lambda B_, N=200, seed=workloads.SEED: workloads.al_tracking(B_, N=N, seed=seed)[:4]}[args.workload]
     if args.scaling == "weak":
         # each rank owns an independent shard of the weak-scaled batch: different seeded perturbations
         prob, x0_q, x0_xi, us0 = make(B, N=N, seed=workloads.SEED + rank)
@@ -365,6 +375,12 @@ def run_rank(args, rank, world):
     solver = BatchedTrackingILQR(prob, B, device=dev)
     x0_q_d = torch.as_tensor(x0_q, device=dev); x0_xi_d = torch.as_tensor(x0_xi, device=dev)
     us0_d = torch.as_tensor(us0, device=dev)
+    if args.workload == "al1024":
+        # ALConstrainedCost + InputConstraint(-10, 10) with the multipliers / penalties of the first outer iteration
+        # (traopt_controller.py:3218-3240: lmbd = 0, Imu = mu0 I): the timed steps are inner MS iterations of that solve
+        lam_d = torch.zeros(B, N, 2 * m, dtype=torch.float64, device=dev)
+        imu_d = torch.full((B, N, 2 * m), 1e-2, dtype=torch.float64, device=dev)
+        solver.set_al([-10.0] * m, [10.0] * m, lam_d, imu_d)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -427,6 +443,14 @@ def run_rank(args, rank, world):
             gather_err = "%s: %s" % (type(e).__name__, e)
     finite = bool(torch.isfinite(res.J_hist[:, :total]).all().item()) if headline else None
     clean = bool((res.status == 0).all().item())
+    # accept-always solves with tolerances 0 must keep every trajectory working to the end: a stopped trajectory (diverged,
+    # status != 0) does no work, and a rate measured over it is not the workload's rate
+    invalid = None
+    if headline and (active_end < 1.0 or not clean or not finite):
+        invalid = ("only %.1f %% of the trajectories were still being solved at the end of the timed regions (status ok: %s, "
+                   "finite: %s): the figure is NOT a valid rate for this workload" % (100 * active_end, clean, finite))
+        if rank == 0:
+            print("bench.py: WARNING: " + invalid, file=sys.stderr)
 
     if rank == 0:
         med = statistics.median(regions)
@@ -443,10 +467,13 @@ def run_rank(args, rank, world):
         std_cfg = args.workload == "se3" and B == 4096 and N == 200 and headline and args.schedule == "auto"
         traffic, traffic_src = measured_traffic(dominant) if std_cfg else (None, None)
         measured_gbs = traffic / (t_dom * 1e-3) / 1e9 if (traffic and t_dom > 0) else None
-        what = {"se3": "SE3 exact tracking", "drone400": "drone racing tracking (BASELINE config 5)"}[args.workload]
+        what = {"se3": "SE3 exact tracking", "drone400": "drone racing tracking (BASELINE config 5; R = 1e-3 I)",
+                "so3": "SO3 exact tracking (BASELINE config 2)",
+                "al1024": "SE3 AL-DDP MS with input box constraints, inner iterations of the first outer iteration "
+                          "(BASELINE config 4)"}[args.workload]
         algo = ("MS-iLQR" if args.mode == "ms" else "SS-iLQR") + (
             " (line_search=%s, rollout=nonlinear)" % ("True" if args.line_search else "False") if args.mode == "ms" else " (13-alpha backtracking)")
-        metric = METRIC if (args.workload == "se3" and headline) else (
+        metric = METRIC if (args.workload == "se3" and headline and B == 4096 and N == 200) else (
             "DDP iterations/sec at batch x horizon = %d x %d (%s, %s)" % (B_global if args.scaling == "strong" else B, N, what, algo))
         line = {
             "metric": metric,
@@ -463,6 +490,7 @@ def run_rank(args, rank, world):
                                        % (B if args.scaling == "weak" else B_global),
                        "trajectory_iterations_per_s": value * (B if args.scaling == "weak" else B_global),
                        "active_fraction_at_region_end": active_end, "all_finite": finite, "all_status_ok": clean,
+                       **({"invalid": invalid} if invalid else {}),
                        "timed_regions": {"repeats": R, "steps_each": K, "reported": "median",
                                          "ms_per_step": [r / K * 1e3 for r in regions],
                                          "min_ms_per_step": min(regions) / K * 1e3,
@@ -491,7 +519,7 @@ def run_rank(args, rank, world):
                                  "25 kflop per knot-iteration at fp64_frac_step of the fp64 vector peak: an fp64 "
                                  "issue / latency-bound sweep that also moves ~7x its algorithmic bytes (DESIGN.md §5)"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload != "al1024":  # (the oracle's batch driver has no AL terms)
             line["cpu_baseline"] = cpu_baseline(prob, x0_q, x0_xi, us0, args.cpu_seconds, args.mode, args.line_search)
         print(json.dumps(line), flush=True)
     if multi:

@@ -107,8 +107,9 @@ def se3_tracking(B, N=200, R_scale=1e-5, seed=SEED):
     return prob, x0_q, x0_xi, np.zeros((B, N, 6))
 
 
-def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED):
-    """Config 5: DroneDynamics on the first N+1 knots of path_dense_random_columns_4obj (dt=0.004)."""
+def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED, perturb=1.0):
+    """Config 5: DroneDynamics on the first N+1 knots of path_dense_random_columns_4obj (dt=0.004).
+    `perturb` scales the spread of the initial states around the nominal one."""
     q_ref, xi_ref, dt = load_reference("drone_columns_n400")
     if not 1 <= N <= q_ref.shape[0] - 1:
         raise ValueError("path_dense_random_columns_4obj (stored part) has %d knots: horizon N must be in [1, %d]"
@@ -120,7 +121,7 @@ def drone_tracking(B, N=400, R_scale=1e-5, seed=SEED):
     q0[:3, :3] = _rot_zxy(1e-4, 0.0, 0.0)
     q0[:3, 3] = q_ref[0][:3, 3] - 0.1
     xi0 = np.ones(6) * 1e-3
-    x0_q, x0_xi = perturbed_batch(q0, xi0, B, 0.1 * np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), 0.01, seed)
+    x0_q, x0_xi = perturbed_batch(q0, xi0, B, perturb * 0.1 * np.array([0.3, 0.3, 0.3, 0.5, 0.5, 0.5]), perturb * 0.01, seed)
     return prob, x0_q, x0_xi, np.zeros((B, N, 4))
 
 
