@@ -67,20 +67,28 @@ def build_extension(force=False, verbose=False, extra_flags=(), lint=True):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the HIP extension cannot be built (and there is no CPU fallback)")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", _SO, _SRC, *extra_flags]
+    # built beside the target and moved into place when it has passed the lint: a process that loads the library while
+    # another one rebuilds it (ranks of one job, pytest-xdist workers) sees the old file or the new one, never half of one
+    tmp = "%s.%d.tmp" % (_SO, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp, _SRC, *extra_flags]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    if lint:
-        # the hand-written DPP blocks run without hazard nops where the emitted code keeps the distance: check that it does
-        from . import _dpp_lint
-        _isa = _dpp_lint.disassemble(_SO)
-        findings = _dpp_lint.lint(_isa) + _dpp_lint.lint_more(_isa)
-        if findings:
-            bad = _SO + ".hazard"
-            os.replace(_SO, bad)
-            raise RuntimeError("DPP read-after-write hazards in the built library (kept as %s):\n%s"
-                               % (bad, "\n".join("%s %x: %s" % f for f in findings[:20])))
+    try:
+        subprocess.check_call(cmd)
+        if lint:
+            # the hand-written DPP blocks run without hazard nops where the emitted code keeps the distance: check that it does
+            from . import _dpp_lint
+            _isa = _dpp_lint.disassemble(tmp)
+            findings = _dpp_lint.lint(_isa) + _dpp_lint.lint_more(_isa)
+            if findings:
+                bad = _SO + ".hazard"
+                os.replace(tmp, bad)
+                raise RuntimeError("DPP read-after-write hazards in the built library (kept as %s):\n%s"
+                                   % (bad, "\n".join("%s %x: %s" % f for f in findings[:20])))
+        os.replace(tmp, _SO)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     with open(_INFO, "w") as f:
         json.dump({"source_sha256_16": source_hash(), "git_head": _git_head(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%S"),
                    "flags": list(extra_flags)}, f)
