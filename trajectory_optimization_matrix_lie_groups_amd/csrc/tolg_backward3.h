@@ -67,10 +67,9 @@ TOLG_DEV void ldl3_update(double (&a)[M], double w) {
 // y += sum_{k < I} p@lane urow(k) * q[k]  (row I of the forward substitution; p = this lane's a[I])
 template <int M, int I, int LO = 0>
 TOLG_DEV void ldl3_fwd_row(double& y, double p, const double (&q)[M]) {
-  // (row 1 opens the substitution: its column may have just come back from an AGPR -- tools/dpp_hazard_lint.py found
-  // exactly that -- so it carries the two wait states itself)
+  // (the wait states between a column's return from an AGPR and its DPP read: ldl3_tie_columns, in front of row 1)
   if constexpr (I == 1)
-    asm volatile("s_nop 1\n\t" DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0) + LO));
+    asm volatile(DF3("%0", "%1", "%2", "%3") : "+v"(y) : "v"(p), "v"(q[0]), "n"(urow<M>(0) + LO));
   if constexpr (I == 2)
     asm volatile(DF3("%0", "%1", "%2", "%4") DF3("%0", "%1", "%3", "%5")
                  : "+v"(y) : "v"(p), "v"(q[0]), "v"(q[1]), "n"(urow<M>(0) + LO), "n"(urow<M>(1) + LO));
@@ -188,9 +187,21 @@ TOLG_DEV bool ldl3_all_positive(const double (&d)[M]) {
   for (int u = 1; u < M; u++) ok = ok && (d[u] > 0.0);
   return ok;
 }
+// Two wait states with the factor columns a[1..M-1] as operands: every one of them is a DPP operand of the rows that
+// follow, and the allocator is free to bring any of them back from an AGPR directly in front of its row (the lint found
+// exactly that in a build whose allocation differed).  Tied to one nop they are in VGPRs here, ahead of all rows.
+template <int M>
+TOLG_DEV void ldl3_tie_columns(const double (&a)[M]) {
+#ifndef TOLG_DPP_BUILTIN
+  double(&w)[M] = const_cast<double(&)[M]>(a);
+  if constexpr (M == 6) asm volatile("s_nop 1" : "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]));
+  else asm volatile("s_nop 1" : "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#endif
+}
 // forward substitution in place: y <- L^-1 y, zn_k = -y_k / Dl_k (nri = -1 / Dl, zeroed in the adjoint lane)
 template <int M, int LO = 0>
 TOLG_DEV void ldl3_forward(const double (&a)[M], const double (&nri)[M], double (&y)[M], double (&zn)[M]) {
+  ldl3_tie_columns<M>(a);
   zn[0] = y[0] * nri[0];
   if constexpr (M > 1) { ldl3_fwd_row<M, 1, LO>(y[1], a[1], zn); zn[1] = y[1] * nri[1]; }
   if constexpr (M > 2) { ldl3_fwd_row<M, 2, LO>(y[2], a[2], zn); zn[2] = y[2] * nri[2]; }
@@ -440,6 +451,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // (Fencing these reads into use order -- the six that open the Z product first, [l_xx | l_x] and l_u behind its first
     // block -- was measured: +0.02 ms.  The compiler's order stays.)
     double A[12], Qh[12], lu[M], luu_i = 0.0;
+    // (Reading the six fields that open the Z product at the end of the previous step -- they are in the other slot by
+    // then -- was measured late in round 3: 0.336 against 0.337 ms, nothing.  Not kept.)
 #pragma unroll
     for (int r = 0; r < 3; r++) { A[r] = ld(oT[r]); A[3 + r] = ld(oM[r]); }
 #pragma unroll
@@ -552,16 +565,23 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     }
     // Q_xx on its way through LDS for the symmetrisation: written here, read back (transposed) a few hundred cycles
     // later -- behind the factorisation / the gradient term / the forward substitution, not in front of the next knot
-    // Every second knot only (the steps of slot 0): between two symmetrisations the antisymmetric part grows by the
-    // factor of two knots (~1.2 measured, 4 at worst), which leaves it at rounding level.
-#ifdef TOLG_K3_SYM1
-    constexpr bool SYM = true;
-#elif TOLG_K3_X == 4 || TOLG_K3_X == 6
-    constexpr bool SYM = false;
-#else
-    constexpr bool SYM = SLOT == 0;
+    // Every TOLG_K3_SYMP-th knot only (knots i = 0 mod 4 by default: a wave-uniform branch around the transpose in the
+    // steps of slot 0): between two symmetrisations the antisymmetric part grows by the factor of that many knots (~1.1 per
+    // knot measured over whole sweeps, 4 at worst: 2.6e-14 of |V| before it is removed), which leaves it at rounding
+    // level.  Period 2 -> 4 (late round 3): -10 instructions per knot on average, 0.335 -> 0.324 ms with the column tie
+    // of ldl3_forward (same box).  Knot 0 is always one of them.
+#ifndef TOLG_K3_SYMP
+#define TOLG_K3_SYMP 4
 #endif
-    if constexpr (SYM) {
+    static_assert(TOLG_K3_SYMP >= 1 && (TOLG_K3_SYMP & (TOLG_K3_SYMP - 1)) == 0, "symmetrisation period: a power of two");
+#if TOLG_K3_X == 4 || TOLG_K3_X == 6
+    constexpr bool sym_now = false;
+#elif TOLG_K3_SYMP <= 2
+    constexpr bool sym_now = TOLG_K3_SYMP == 1 || SLOT == 0;
+#else
+    const bool sym_now = SLOT == 0 && (i & (TOLG_K3_SYMP - 1)) == 0;
+#endif
+    if (sym_now) {
 #pragma unroll
       for (int r = 0; r < 12; r++) *reinterpret_cast<double*>(lds + wTR + r * (B3_TRS * 8)) = Qh[r];
     }
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       }
     };
     auto symmetrise = [&]() {
-      if constexpr (!SYM) return;
+      if (!sym_now) return;
       read_T();
 #pragma unroll
       for (int r = 0; r < 12; r++) Qh[r] = hsym * (Qh[r] + T[r]);
