@@ -88,9 +88,28 @@ def test_further_rules_on_synthetic_disassembly(seq, n_findings):
     assert len(_dpp_lint.lint_more(t)) == n_findings, _dpp_lint.lint_more(t)
 
 
-def test_branch_target_in_window_is_reported():
-    t = HEAD + _ins("s_cbranch_execz 2 ", 0).replace("//", "// 0 <k+0x10>") + _ins("v_add_f64 v[30:31], v[0:1], v[2:3]", 8) + DPP % 0x10
-    assert any("branch target" in f[2] for f in _dpp_lint.lint(t))
+def _label(text, addr, target_off):
+    return ("\t%s // 000000001%03X: 0 <k+0x%x>\n" % (text, addr, target_off))
+
+
+def test_branch_into_the_window_is_followed_to_its_source():
+    # the writer sits in front of a branch that jumps straight to the DPP read: the branch is the only wait state between them
+    t = (HEAD + _ins("v_add_f64 v[4:5], v[0:1], v[2:3]", 0) + _label("s_cbranch_execz 4", 8, 0x20) + _ins("s_nop 7", 0x10)
+         + _ins("s_nop 7", 0x18) + DPP % 0x20)
+    f = _dpp_lint.lint(t)
+    assert len(f) == 1 and "v_add_f64 at 1000" in f[0][2]
+    # one more instruction behind the target: branch + instruction = the two wait states
+    t = (HEAD + _ins("v_add_f64 v[4:5], v[0:1], v[2:3]", 0) + _label("s_cbranch_execz 4", 8, 0x20) + _ins("s_nop 7", 0x10)
+         + _ins("s_nop 7", 0x18) + _ins("v_add_f64 v[30:31], v[0:1], v[2:3]", 0x20) + DPP % 0x28)
+    assert _dpp_lint.lint(t) == []
+    # a harmless instruction in front of the branch: both predecessors of the target are clean
+    t = (HEAD + _ins("v_add_f64 v[8:9], v[0:1], v[2:3]", 0) + _label("s_cbranch_execz 4", 8, 0x20) + _ins("s_nop 7", 0x10)
+         + _ins("s_nop 7", 0x18) + DPP % 0x20)
+    assert _dpp_lint.lint(t) == []
+    # an unconditional branch has no fall-through: the writer in front of it is not a predecessor of what follows
+    t = (HEAD + _label("s_cbranch_scc1 3", 0, 0x18) + _ins("v_add_f64 v[4:5], v[0:1], v[2:3]", 8) + _label("s_branch 9", 0x10, 0x60)
+         + DPP % 0x18)
+    assert _dpp_lint.lint(t) == []
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(_dpp_lint.LLVM, "llvm-objdump")), reason="no llvm-objdump")

@@ -26,7 +26,9 @@ see through an inline-asm statement -- checked over ALL code, so the compiler's 
   6. EXEC written by a VALU instruction (v_cmpx) in front of a DPP instruction: 5;
   7. M0 written by a scalar instruction in front of an LDS-DMA load (`global_load_lds_*`, `buffer_load_* ... lds`): 1.
 
-A branch target inside the window is reported as well (the other predecessor cannot be seen in a linear scan).
+Rule 1 follows control flow: at a branch target inside the window the scan continues along the fall-through predecessor
+and from every branch that jumps there (an earlier version reported the target itself, which refused builds whose other
+predecessor was harmless).
 
     python tools/dpp_hazard_lint.py [path/to/libtolg_hip.so]      exit code 1 on a finding
 
@@ -84,80 +86,107 @@ def _is_valu(op):
     return op.startswith("v_") and not op.startswith("v_nop")
 
 
-def lint(text):
-    """-> list of (kernel, address, message)"""
-    findings = []
+def _is_dpp(op, args):
+    return op.endswith("_dpp") or any(k in args for k in ("row_newbcast", "row_shl", "row_shr", "quad_perm", "row_bcast", "row_ror",
+                                                            "row_mirror", "wave_", "row_half_mirror"))
+
+
+def _parse(text):
+    """-> {kernel: [(address, opcode, args)]}, {kernel: {target address: [indices of the branches that jump there]}}"""
+    kernels, order, base = {}, [], {}
     kernel = None
-    window = []  # (wait_states, opcode, written regs, address, is_label)
-    swindow = []  # the same for VALU writes of SGPRs
-    targets = set()
-    lines = text.splitlines()
-    # branch targets: objdump prints them as <symbol+0xOFF> in the comment of the branch
-    for ln in lines:
-        m = re.search(r"s_c?branch\S*\s.*<([^>+]+)\+0x([0-9a-f]+)>", ln)
-        if m:
-            targets.add((m.group(1), int(m.group(2), 16)))
-    base = 0
-    for ln in lines:
+    raw_targets = []
+    for ln in text.splitlines():
         m = re.match(r"^([0-9a-f]+) <(.+)>:$", ln)
         if m:
-            kernel, base, window, swindow = m.group(2), int(m.group(1), 16), [], []
+            kernel = m.group(2)
+            kernels[kernel] = []
+            base[kernel] = int(m.group(1), 16)
             continue
         m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
         if not m or kernel is None:
             continue
         op, args, addr = m.group(1), m.group(2), int(m.group(3), 16)
-        is_target = (kernel, addr - base) in targets
-        if is_target:
-            window.append((0, "<label>", set(), addr, True))
-        if "row_newbcast" in args or "row_shl" in args or "row_shr" in args or "quad_perm" in args or "row_bcast" in args \
-                or "row_ror" in args or "row_mirror" in args or "wave_" in args or "row_half_mirror" in args or op.endswith("_dpp"):
+        kernels[kernel].append((addr, op, args))
+        t = re.search(r"<([^>+]+)\+0x([0-9a-f]+)>", ln) if re.match(r"s_c?branch", op) else None
+        if t:
+            raw_targets.append((kernel, len(kernels[kernel]) - 1, t.group(1), int(t.group(2), 16)))
+    sources = {k: {} for k in kernels}
+    for k, idx, sym, off in raw_targets:
+        if sym in base and sym == k:
+            sources[k].setdefault(base[k] + off, []).append(idx)
+    return kernels, sources
+
+
+def lint(text):
+    """Rules 1 and 2 -> list of (kernel, address, message).  Rule 1 follows control flow: at a branch target the scan goes
+    on along the fall-through predecessor AND from every branch that jumps there (a branch is one wait state itself)."""
+    findings = []
+    kernels, sources = _parse(text)
+    for kernel, ins in kernels.items():
+        src = sources[kernel]
+
+        def vwrites(op, args):
+            if not _is_valu(op) or op.startswith("v_cmp") or op.startswith("v_accvgpr_write"):
+                return set()
             toks = [t.strip() for t in args.split(",")]
-            # src0 is the DPP operand: the second token (after the destination)
-            src0 = _regs(toks[1].split()[0]) if len(toks) > 1 else set()
-            ws = 0
-            for w_ws, w_op, w_regs, w_addr, w_label in reversed(window):
-                if ws >= 2:
-                    break
-                if w_label:
-                    findings.append((kernel, addr, "branch target %d wait state(s) in front of %s (DPP operand v%s)" % (ws, op, sorted(src0))))
-                    continue
-                if _is_valu(w_op) and (w_regs & src0):
-                    findings.append((kernel, addr, "%s reads v%s through DPP %d wait state(s) after %s at %x wrote it"
-                                     % (op, sorted(w_regs & src0), ws, w_op, w_addr)))
-                ws += w_ws
-        if _is_vmem(op):
-            sread = _sregs(args)
-            ws = 0
-            for w_ws, w_op, w_regs, w_addr, w_label in reversed(swindow):
-                if ws >= 5:
-                    break
-                if w_regs & sread:
-                    findings.append((kernel, addr, "%s reads s%s %d wait state(s) after %s at %x wrote it (VALU write of an SGPR -> "
-                                     "vector memory: 5)" % (op, sorted(w_regs & sread), ws, w_op, w_addr)))
-                ws += w_ws
-        # record this instruction
-        if op == "s_nop":
-            n = int(args.split()[0], 0) if args else 0
-            window.append((n + 1, op, set(), addr, False))
-            swindow.append((n + 1, op, set(), addr, False))
-        else:
-            toks = [t.strip() for t in args.split(",")]
-            written = _regs(toks[0]) if toks and _is_valu(op) and not op.startswith("v_cmp") else set()
-            if op.startswith("v_accvgpr_write"):
-                written = set()
-            window.append((1, op, written, addr, False))
-            # SGPRs a VALU instruction writes: the destination of readlane / readfirstlane, explicit carry / compare outputs
-            swritten = set()
-            if _is_valu(op) and toks:
-                if op.startswith(("v_readfirstlane", "v_readlane")) or "_co_" in op or op.startswith(("v_cmp", "v_div_scale")):
-                    swritten = _sregs(toks[0]) | (_sregs(toks[1]) if ("_co_" in op or op.startswith("v_div_scale")) and len(toks) > 1 else set())
-            swindow.append((1, op, swritten, addr, False))
-        if len(window) > 8:
-            window = window[-8:]
-        if len(swindow) > 12:
+            return _regs(toks[0]) if toks else set()
+
+        def walk(i, ws, src0, op_d, addr_d, depth, seen):
+            """instructions in front of index i (exclusive), `ws` wait states already between them and the DPP read"""
+            k = i - 1
+            while ws < 2 and k >= 0:
+                a, op, args = ins[k]
+                # is the instruction BEHIND k (index k + 1) a branch target?  then every branch to it is a predecessor too
+                if ins[k + 1][0] in src and depth < 4:
+                    for s in src[ins[k + 1][0]]:
+                        if (s, ws) not in seen:
+                            seen.add((s, ws))
+                            walk(s + 1, ws, src0, op_d, addr_d, depth + 1, seen)
+                if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    return  # no fall-through from here
+                w = vwrites(op, args)
+                if w & src0:
+                    findings.append((kernel, addr_d, "%s reads v%s through DPP %d wait state(s) after %s at %x wrote it"
+                                     % (op_d, sorted(w & src0), ws, op, a)))
+                ws += (int(args.split()[0], 0) + 1) if (op == "s_nop" and args) else 1
+                k -= 1
+            if ws < 2 and k < 0 and depth == 0:
+                pass  # kernel entry: nothing in front
+
+        swindow = []
+        for i, (addr, op, args) in enumerate(ins):
+            if _is_dpp(op, args):
+                toks = [t.strip() for t in args.split(",")]
+                src0 = _regs(toks[1].split()[0]) if len(toks) > 1 else set()  # src0 is the DPP operand
+                walk(i, 0, src0, op, addr, 0, set())
+            if _is_vmem(op):
+                sread = _sregs(args)
+                ws = 0
+                for w_ws, w_op, w_regs, w_addr in reversed(swindow):
+                    if ws >= 5:
+                        break
+                    if w_regs & sread:
+                        findings.append((kernel, addr, "%s reads s%s %d wait state(s) after %s at %x wrote it (VALU write of an SGPR -> "
+                                         "vector memory: 5)" % (op, sorted(w_regs & sread), ws, w_op, w_addr)))
+                    ws += w_ws
+            if op == "s_nop":
+                swindow.append(((int(args.split()[0], 0) if args else 0) + 1, op, set(), addr))
+            else:
+                toks = [t.strip() for t in args.split(",")]
+                swritten = set()
+                if _is_valu(op) and toks:
+                    if op.startswith(("v_readfirstlane", "v_readlane")) or "_co_" in op or op.startswith(("v_cmp", "v_div_scale")):
+                        swritten = _sregs(toks[0]) | (_sregs(toks[1]) if ("_co_" in op or op.startswith("v_div_scale")) and len(toks) > 1 else set())
+                swindow.append((1, op, swritten, addr))
             swindow = swindow[-12:]
-    return findings
+    # one finding per (DPP instruction, writer): paths that merge report the same pair twice
+    out, seen_f = [], set()
+    for f in findings:
+        if f not in seen_f:
+            seen_f.add(f)
+            out.append(f)
+    return out
 
 
 _TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
