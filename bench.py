@@ -200,6 +200,29 @@ def library_identity(allow_override):
 # ---------------------------------------------------------------------------------------------------
 # measurement
 # ---------------------------------------------------------------------------------------------------
+def fp64_issue_fraction(kernel, t_ms):
+    """Fraction of the chip's fp64 vector ISSUE rate the kernel ran at: fp64 instructions it executed (SQ_INSTS_VALU_{FMA,
+    MUL,ADD,TRANS}_F64 of the newest committed profiles/*_sq_mix.json, per wave x waves per launch) over what 1 024 SIMDs
+    issue in its measured time at one wave-instruction per four cycles of the 2.4 GHz peak clock.  None without a profile."""
+    import glob
+    loaded = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_mix.json")):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        loaded.append(((d.get("captured", ""), os.path.basename(f)), f, d))   # newest capture; files without a stamp sort first
+    for _key, f, d in sorted(loaded, reverse=True):
+        ks = d.get("kernels", {})
+        for name, v in ks.items():
+            if kernel in name and "SQ_WAVES" in v and t_ms > 0:
+                n = sum(v.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("FMA", "MUL", "ADD", "TRANS"))   # summed over the waves of a launch
+                peak = 1024 * 2.4e9 / 4.0
+                return {"fp64_instructions_per_launch": n, "issue_rate": n / (t_ms * 1e-3), "peak_issue_rate": peak,
+                        "frac": n / (t_ms * 1e-3) / peak, "source": os.path.basename(f)}
+    return None
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes
     (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of the default
@@ -512,6 +535,7 @@ def run_rank(args, rank, world):
                          "frac_dominant_kernel": (dom_gbs / HBM_PEAK_GBS) if dom_gbs else None,
                          "measured_achieved_dominant_kernel": measured_gbs,
                          "measured_frac_of_achievable_dominant_kernel": (measured_gbs / HBM_ACHIEVABLE_GBS) if measured_gbs else None,
+                         "fp64_issue_dominant_kernel": fp64_issue_fraction(dominant, t_dom) if std_cfg else None,
                          "fp64_frac_step": ALG_FLOPS_PER_KNOT_ITER * B * N / (ms_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                          "note": "bound named as BASELINE.json stipulates (HBM); by the numbers the step moves its "
                                  "algorithmic bytes at frac of the HBM peak while the dominant kernel's MEASURED traffic "

@@ -22,7 +22,8 @@ for r in csv.DictReader(open("gpurun_out/${tag}_pmc_$p/run_counter_collection.cs
     k=r["Kernel_Name"].split("(")[0]
     if not any(t in k for t in ("k_rollout","k_backward","k_linearize","k_rollout_lin")): continue
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
-out={"note":"rocprofv3 --kernel-trace --pmc $ctr (one pass) over python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline (4096x200 SE3); per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles summed over waves","kernels":{}}
+import time
+out={"captured":time.strftime("%Y-%m-%dT%H:%M:%SZ",time.gmtime()),"note":"rocprofv3 --kernel-trace --pmc $ctr (one pass) over python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline (4096x200 SE3); per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles summed over waves","kernels":{}}
 for k in acc:
     n=len(cnt[k]); d={c:v/n for c,v in acc[k].items()}
     d["launches"]=n
