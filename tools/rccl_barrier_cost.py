@@ -1,3 +1,6 @@
+"""What the barrier around a timed region of bench.py costs on this box: dist.barrier() against a one-element all-reduce
++ synchronize, RCCL process group of one rank (25 us / 19 us on an MI355X: not what separates a cold region from a warm one).
+    python tools/rccl_barrier_cost.py"""
 import os, time, torch, torch.distributed as dist, datetime
 os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29544"); os.environ.setdefault("RANK","0"); os.environ.setdefault("WORLD_SIZE","1")
 torch.cuda.set_device(0); dev=torch.device("cuda",0)
