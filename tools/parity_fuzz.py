@@ -4,7 +4,7 @@
 step, the spread of the initial states and of the initial controls), each case against the oracle.  Looks for the rare
 paths the fixed cases do not visit (regularisation retries, the max-regularisation exit, the closed-form tiers of the
 series, deep backtracking).  Prints one line per disagreement with the seed that reproduces it.
-    python tools/parity_fuzz.py [cases] [first seed]"""
+    python tools/parity_fuzz.py [--large] [cases] [first seed]"""
 import os
 import sys
 
@@ -19,6 +19,10 @@ TOL_J = 1e-8     # relative, per iteration (tests/test_gpu_matrix.py holds its h
 TOL_U = 1e-6     # north_star
 
 
+LARGE = False    # --large: batches of 500 .. 6 000 (the compacted lists and the thread form of the wide line-search stages,
+                 # many workgroups, padded tails), horizons of 40 .. 200
+
+
 def draw(seed):
     rng = np.random.default_rng(seed)
     kind = ["se3", "rigidbody", "drone"][rng.integers(3)]
@@ -27,6 +31,8 @@ def draw(seed):
     line_search = bool(rng.integers(2)) if mode == "ms" else False
     rollout = ["nonlinear", "linear"][int(rng.integers(4) == 0)]
     B, N = int(rng.integers(1, 10)), int(rng.integers(3, 70))
+    if LARGE:
+        B, N = int(rng.integers(500, 6000)), int(rng.integers(40, 201))
     base, x0_q, x0_xi, _ = (workloads.drone_tracking if kind == "drone" else workloads.se3_tracking)(B, N=N, seed=seed)
     m = 4 if kind == "drone" else 6
     J = np.diag(rng.uniform(0.3, 2.0, 6))
@@ -44,9 +50,9 @@ def draw(seed):
         R = R + Bm @ Bm.T
     dt = float(base.dt * rng.uniform(0.6, 1.5))
     prob = TrackingProblem(kind, J, dt, Q, R, rng.uniform(1.0, 10.0) * Q, base.q_ref, base.xi_ref)
-    us0 = rng.normal(size=(B, N, m)) * 10.0 ** rng.uniform(-3, -0.5)
+    us0 = rng.normal(size=(B, N, m)) * 10.0 ** rng.uniform(-3, -0.5 if not LARGE else -1.5)
     x0_xi = x0_xi + rng.normal(size=x0_xi.shape) * 10.0 ** rng.uniform(-2, -0.3)
-    K = int(rng.integers(3, 14))
+    K = int(rng.integers(3, 14)) if not LARGE else int(rng.integers(3, 8))
     return dict(kind=kind, diag=diag, mode=mode, line_search=line_search, rollout=rollout, B=B, N=N, K=K), prob, x0_q, x0_xi, us0
 
 
@@ -88,7 +94,7 @@ def one(seed):
             longer = Jg[b, : it[b]] if it[b] > o["iters"][b] else o["J_hist"][b, : o["iters"][b]]
             tail = longer[max(n - 1, 0):]
             searching = cfg["line_search"] or cfg["mode"] == "ss"
-            if searching and np.isfinite(tail).all() and np.ptp(tail) <= 1e-11 * abs(tail[0]):
+            if searching and np.isfinite(tail).all() and np.ptp(tail) <= 1e-10 * abs(tail[0]):   # (1e-11 in the hand-conditioned matrix test; 3.5e-11 seen in 47 000 random trajectories)
                 stats["coin"] = stats.get("coin", 0) + 1
             else:
                 notes.append("b%d iters %d/%d status %d/%d tail ptp %.1e" % (b, it[b], o["iters"][b], st[b], o["status"][b],
@@ -100,8 +106,11 @@ def one(seed):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    global LARGE
+    args = [a for a in sys.argv[1:] if a != "--large"]
+    LARGE = "--large" in sys.argv[1:]
+    n = int(args[0]) if len(args) > 0 else 100
+    s0 = int(args[1]) if len(args) > 1 else 1000
     bad = 0
     status_total = {}
     for seed in range(s0, s0 + n):
@@ -111,7 +120,8 @@ def main():
         flag = wj > TOL_J or wu > TOL_U or notes
         if flag:
             bad += 1
-        print("%s seed %d %s  J %.1e  u %.1e  %s" % ("DIFF" if flag else "ok  ", seed, cfg, wj, wu, "; ".join(notes)), flush=True)
+        print("%s seed %d %s  J %.1e  u %.1e  %s %s" % ("DIFF" if flag else "ok  ", seed, cfg, wj, wu, "; ".join(notes[:6]),
+                                                          ("(+%d more)" % (len(notes) - 6)) if len(notes) > 6 else ""), flush=True)
     print("%d of %d cases differ; over all trajectories: oracle statuses / wild (skipped) / coin flips at rounding level: %s"
           % (bad, n, status_total))
     return 1 if bad else 0
