@@ -8,10 +8,11 @@ np.set_printoptions(precision=6, linewidth=200)
 for seed in [int(a) for a in sys.argv[1:]]:
     cfg, prob, x0_q, x0_xi, us0 = pf.draw(seed)
     K, B = cfg["K"], cfg["B"]
-    print("=====", seed, cfg, "dt", prob.dt)
-    solver = BatchedTrackingILQR(prob, B)
+    print("=====", seed, cfg, "dt", (prob[0] if isinstance(prob, tuple) else prob).dt)
+    solver = BatchedTrackingILQR(prob[0] if isinstance(prob, tuple) else prob, B)
     r = solver.fit_batch(x0_q, x0_xi, us0, mode=cfg["mode"], n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0, line_search=cfg["line_search"], rollout=cfg["rollout"])
-    op = ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
+    op = prob[1] if isinstance(prob, tuple) else ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
+    prob = prob[0] if isinstance(prob, tuple) else prob
     o = ob.fit_batch(op, x0_q, x0_xi, us0, mode=cfg["mode"], max_iter=K, line_search=cfg["line_search"], rollout=cfg["rollout"])
     it, st, Jg = r.iters.cpu().numpy(), r.status.cpu().numpy(), r.J_hist.cpu().numpy()
     Ag = r.alpha_hist.cpu().numpy() if r.alpha_hist is not None else None
