@@ -169,11 +169,13 @@ template <int M, int J = 0, int LO = 0>
 TOLG_DEV void ldl3_factor(double (&a)[M], double (&nri)[M], double (&d)[M], const double (&wm)[M]) {
   double pre;
   ldl3_head<M, J, LO>(a, wm[J], d[J], pre);
-  // -1 / d: v_rcp_f64 of -d, two Newton steps on x -> x + x (1 + d x).  A non-positive pivot leaves garbage behind it:
+  // -1 / d: v_rcp_f64 of -d, refined (below).  A non-positive pivot leaves garbage behind it:
   // the caller discards the factors then.  (One step instead of two, 2.2e-15, was measured and is no faster.)
+  // (late round 3: ONE third-order step x (1 + e + e^2), e = 1 + d x, instead of two Newton steps -- three dependent
+  // multiply-adds instead of four, and e^3 ~ 1e-22 is below the e^4 of the pair only on paper: both are exact to the last bit)
   double x = __builtin_amdgcn_rcp(-d[J]);
-  x = fma(x, fma(d[J], x, 1.0), x);
-  x = fma(x, fma(d[J], x, 1.0), x);
+  const double e = fma(d[J], x, 1.0);
+  x = fma(e, fma(x, e, x), x);
   nri[J] = x;
   if constexpr (J + 1 < M) {
     ldl3_update<M, J, urow<M>(J) + LO>(a, pre * x);  // a[i] -= a[i]@pivot lane * a[J] / d for the columns right of the pivot
@@ -611,9 +613,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       }
       const double s_ = s0 + s1;
       // sqrt(s) = s rsqrt(s), v_rsq_f64 + one refinement step (4e-15 relative: the gradient norm is compared with 1e-6)
-      double y = __builtin_amdgcn_rsq(s_);
-      { const double g_ = s_ * y, h_ = 0.5 * y; y = 2.0 * fma(h_, fma(-h_, g_, 0.5), h_); }
-      gsum += (s_ > 0.0) ? s_ * y : 0.0;
+      // (late round 3: the step on the root itself, r' = r + (y / 2)(s - r^2) with r = s y -- four instructions behind the
+      // v_rsq_f64 instead of six, the same quadratic convergence)
+      const double y = __builtin_amdgcn_rsq(s_);
+      const double r_ = s_ * y, h_ = 0.5 * y;
+      const double rt = fma(h_, fma(-r_, r_, s_), r_);
+      gsum += (s_ > 0.0) ? rt : 0.0;
     };
     // what follows a settled factorisation: forward substitution, V <- sym(Q_xx) - Y^T Dl^-1 Y (== Eq. 11b/11c of
     // traopt_controller.py:2998-3004 for the exact gains), back substitution in place, gains [K | k] = D^-1 nx
