@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["ms", "ss"], default=None, help="default ms (ss for --workload so3)")
     ap.add_argument("--line-search", action="store_true")
     ap.add_argument("--schedule", choices=["auto", "split"], default="auto")
+    ap.add_argument("--r-scale", type=float, default=None,
+                    help="input weight R = r I of the se3 / drone400 workloads (default 1e-5 / 1e-3); not the metric's workload when set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--allow-lib-override", action="store_true",
@@ -383,8 +385,10 @@ def run_rank(args, rank, world):
     # drone400: R = 1e-3 I.  With the R = 1e-5 of benchmark_drone_racing_tracking.py:208 (a 150-knot problem) accept-always MS
     # diverges on the 400-knot problem for nearly every member -- in the oracle as on the GPU, tests/test_gpu_configs.py --
     # and a diverged trajectory stops doing work: tools/drone_spread_survival.py, profiles/r03_drone_spread_survival.txt
-    drone = lambda B_, N=400, seed=workloads.SEED: workloads.drone_tracking(B_, N=N, seed=seed, R_scale=1e-3)
-    make = {"se3": workloads.se3_tracking, "drone400": drone, "so3": workloads.so3_tracking,
+    drone = lambda B_, N=400, seed=workloads.SEED: workloads.drone_tracking(B_, N=N, seed=seed, R_scale=args.r_scale or 1e-3)
+    se3 = (lambda B_, N=200, seed=workloads.SEED: workloads.se3_tracking(B_, N=N, seed=seed, R_scale=args.r_scale)) if args.r_scale \
+        else workloads.se3_tracking
+    make = {"se3": se3, "drone400": drone, "so3": workloads.so3_tracking,
             "al1024": lambda B_, N=200, seed=workloads.SEED: workloads.al_tracking(B_, N=N, seed=seed)[:4]}[args.workload]
     if args.scaling == "weak":
         # each rank owns an independent shard of the weak-scaled batch: different seeded perturbations
@@ -487,7 +491,7 @@ def run_rank(args, rank, world):
                                ("k_linearize", kl)), key=lambda kv: kv[1])
         dom_gbs = alg_bytes / (t_dom * 1e-3) / 1e9 if t_dom > 0 else None
         step_gbs = alg_bytes / (ms_step * 1e-3) / 1e9
-        std_cfg = args.workload == "se3" and B == 4096 and N == 200 and headline and args.schedule == "auto"
+        std_cfg = args.workload == "se3" and B == 4096 and N == 200 and headline and args.schedule == "auto" and not args.r_scale
         traffic, traffic_src = measured_traffic(dominant) if std_cfg else (None, None)
         measured_gbs = traffic / (t_dom * 1e-3) / 1e9 if (traffic and t_dom > 0) else None
         what = {"se3": "SE3 exact tracking", "drone400": "drone racing tracking (BASELINE config 5; R = 1e-3 I)",
@@ -496,7 +500,9 @@ def run_rank(args, rank, world):
                           "(BASELINE config 4)"}[args.workload]
         algo = ("MS-iLQR" if args.mode == "ms" else "SS-iLQR") + (
             " (line_search=%s, rollout=nonlinear)" % ("True" if args.line_search else "False") if args.mode == "ms" else " (13-alpha backtracking)")
-        metric = METRIC if (args.workload == "se3" and headline and B == 4096 and N == 200) else (
+        if args.r_scale:
+            what += " [R = %g I]" % args.r_scale
+        metric = METRIC if (args.workload == "se3" and headline and B == 4096 and N == 200 and not args.r_scale) else (
             "DDP iterations/sec at batch x horizon = %d x %d (%s, %s)" % (B_global if args.scaling == "strong" else B, N, what, algo))
         line = {
             "metric": metric,
