@@ -419,20 +419,31 @@ def run_rank(args, rank, world):
     regions, kern = [], []
     begin_kw = dict(mode=args.mode, tol_grad_norm=0.0, tol_d_norm=0.0, schedule=args.schedule, line_search=args.line_search)
 
+    # Per-kernel durations need a HIP event in front of and behind every launch, and those marker packets cost the step
+    # 15 us of its 610 (tools/event_cost.py: 614 against 600 us at 4096 x 200).  So the regions alternate: even ones carry the
+    # events (-> kernel_ms_per_step, the roofline's kernel figures), odd ones run the library as a caller runs it (-> value,
+    # ms_per_step).  Both series are in the line.  With one region only (--repeats 1: the profiling runs) it carries the events.
+    instrumented = []
+
     def timed_region():
-        solver.enable_timing(True)
+        instr = len(regions) % 2 == 0
+        solver.enable_timing(instr)
         barrier()
         t0 = time.perf_counter()
         solver.solve_iterate(K)
         barrier()
         t1 = time.perf_counter()
-        ms_b, ms_r, ms_l, n_b = solver.kernel_time(reset=True)
+        if instr:
+            ms_b, ms_r, ms_l, n_b = solver.kernel_time(reset=True)
+            kern.append((ms_b / max(n_b, 1), ms_r / max(n_b, 1), ms_l / max(n_b, 1)))
+        else:
+            kern.append(None)
         solver.enable_timing(False)
         el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
         if multi:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         regions.append(float(el.item()))
-        kern.append((ms_b / max(n_b, 1), ms_r / max(n_b, 1), ms_l / max(n_b, 1)))
+        instrumented.append(instr)
 
     if headline:
         # accept-always MS with tolerances 0: every trajectory does full work in every iteration of one long solve
@@ -480,8 +491,11 @@ def run_rank(args, rank, world):
             print("bench.py: WARNING: " + invalid, file=sys.stderr)
 
     if rank == 0:
-        med = statistics.median(regions)
-        imed = min(range(R), key=lambda i: abs(regions[i] - med))
+        plain = [r for r, ins in zip(regions, instrumented) if not ins]
+        with_ev = [r for r, ins in zip(regions, instrumented) if ins]
+        med = statistics.median(plain if plain else with_ev)
+        med_ev = statistics.median(with_ev)
+        imed = min((i for i in range(R) if instrumented[i]), key=lambda i: abs(regions[i] - med_ev))
         kb, kr, kl = kern[imed]
         # weak: every rank advanced its own --batch trajectories K times; strong: the one global batch K times
         value = (world if args.scaling == "weak" else 1) * K / med
@@ -520,11 +534,20 @@ def run_rank(args, rank, world):
                        "trajectory_iterations_per_s": value * (B if args.scaling == "weak" else B_global),
                        "active_fraction_at_region_end": active_end, "all_finite": finite, "all_status_ok": clean,
                        **({"invalid": invalid} if invalid else {}),
-                       "timed_regions": {"repeats": R, "steps_each": K, "reported": "median",
+                       "timed_regions": {"repeats": R, "steps_each": K,
+                                         "reported": ("median of the regions WITHOUT per-kernel events (odd ones); kernel_ms_per_step "
+                                                      "from the median region WITH them (even ones)") if plain else
+                                                     "the only region(s) carry the per-kernel events",
                                          "ms_per_step": [r / K * 1e3 for r in regions],
+                                         "with_kernel_events": instrumented,
+                                         "median_ms_per_step_with_kernel_events": med_ev / K * 1e3,
                                          "min_ms_per_step": min(regions) / K * 1e3,
                                          "max_ms_per_step": max(regions) / K * 1e3},
                        "kernel_ms_per_step": {"backward": kb, "rollout": kr, "linearize": kl},
+                       "kernel_ms_per_step_note": "HIP events around every launch, measured in the regions that carry them (whose "
+                                                  "median step is timed_regions.median_ms_per_step_with_kernel_events, not "
+                                                  "ms_per_step): an event pair brackets a little more than its kernel, and "
+                                                  "the marker packets lengthen the step by ~15 us",
                        **({"rccl_selftest": "process group of one rank: barrier, all_reduce(MAX), all_gather ran on the device"}
                           if (args.rccl_selftest and world == 1) else {}),
                        "final_gather_ms": gather_ms, **({"final_gather_error": gather_err} if gather_err else {}),
