@@ -419,8 +419,8 @@ def run_rank(args, rank, world):
     regions, kern = [], []
     begin_kw = dict(mode=args.mode, tol_grad_norm=0.0, tol_d_norm=0.0, schedule=args.schedule, line_search=args.line_search)
 
-    # Per-kernel durations need a HIP event in front of and behind every launch, and those marker packets cost the step
-    # 15 us of its 610 (tools/event_cost.py: 614 against 600 us at 4096 x 200).  So the regions alternate: even ones carry the
+    # Per-kernel durations need an event pair per launch, and timing costs the step 11 us of its 600 (tools/event_cost.py:
+    # 607 against 596 us at 4096 x 200 with the pair attached to the dispatch; 614 with marker packets around it).  So the regions alternate: even ones carry the
     # events (-> kernel_ms_per_step, the roofline's kernel figures), odd ones run the library as a caller runs it (-> value,
     # ms_per_step).  Both series are in the line.  With one region only (--repeats 1: the profiling runs) it carries the events.
     instrumented = []
@@ -544,10 +544,10 @@ def run_rank(args, rank, world):
                                          "min_ms_per_step": min(regions) / K * 1e3,
                                          "max_ms_per_step": max(regions) / K * 1e3},
                        "kernel_ms_per_step": {"backward": kb, "rollout": kr, "linearize": kl},
-                       "kernel_ms_per_step_note": "HIP events around every launch, measured in the regions that carry them (whose "
-                                                  "median step is timed_regions.median_ms_per_step_with_kernel_events, not "
-                                                  "ms_per_step): an event pair brackets a little more than its kernel, and "
-                                                  "the marker packets lengthen the step by ~15 us",
+                       "kernel_ms_per_step_note": "a HIP event pair per launch (attached to the dispatch of the two hot kernels), measured in the "
+                                                  "regions that carry them, whose median step is "
+                                                  "timed_regions.median_ms_per_step_with_kernel_events, not ms_per_step: timing "
+                                                  "lengthens the step by ~11 us",
                        **({"rccl_selftest": "process group of one rank: barrier, all_reduce(MAX), all_gather ran on the device"}
                           if (args.rccl_selftest and world == 1) else {}),
                        "final_gather_ms": gather_ms, **({"final_gather_error": gather_err} if gather_err else {}),

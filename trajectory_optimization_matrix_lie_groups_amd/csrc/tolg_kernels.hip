@@ -13,6 +13,7 @@
 // Device layout: structure-of-arrays with the batch index fastest, poses as unit quaternion +
 // translation (see tolg_lie.h).  The 4x4 layout of the reference exists only at the C ABI.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <math.h>
 #include <stdint.h>
@@ -3385,8 +3386,12 @@ extern "C" void tolg_enable_timing(tolg_handle_t h, int32_t on) {
 
 namespace {
 struct Timed {
-  tolg_handle_s* h; hipStream_t st; int kind; bool on;
-  Timed(tolg_handle_s* h_, hipStream_t s, int k) : h(h_), st(s), kind(k) {
+  // Two ways to time what a scope launches.  The general one records an event in front of and behind whatever the scope
+  // puts on the stream -- two marker packets, which cost the stream ~7 us per pair.  The one for a scope that is ONE kernel
+  // (`ext`: the backward sweep's third form, the fused launch) hands the event pair to the dispatch itself
+  // (hipExtLaunchKernelGGL: start / stop timestamps of the kernel's own completion signal, no extra packet).
+  tolg_handle_s* h; hipStream_t st; int kind; bool on, ext;
+  Timed(tolg_handle_s* h_, hipStream_t s, int k, bool ext_ = false) : h(h_), st(s), kind(k), ext(ext_) {
     on = h->timing;
     if (on && h->ev_used == h->ev_kind.size()) {  // grow the event pool: a long solve must not silently stop being timed
       const size_t n = h->ev_kind.size() + 1024;
@@ -3395,10 +3400,18 @@ struct Timed {
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev.resize(2 * h->ev_kind.size()); on = false; break; }
       if (on) h->ev_kind.resize(n);
     }
-    if (on) (void)hipEventRecord(h->ev[2 * h->ev_used], st);
+    if (on && !ext) (void)hipEventRecord(h->ev[2 * h->ev_used], st);
+  }
+  template <typename F, typename... Args>
+  void launch(F kernel, dim3 grid, dim3 blk, Args... args) {  // (ext scopes: exactly one call)
+    if (on && ext) hipExtLaunchKernelGGL(kernel, grid, blk, 0, st, h->ev[2 * h->ev_used], h->ev[2 * h->ev_used + 1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, blk, 0, st, args...);
   }
   ~Timed() {
-    if (on) { (void)hipEventRecord(h->ev[2 * h->ev_used + 1], st); h->ev_kind[h->ev_used] = kind; h->ev_used++; }
+    if (on) {
+      if (!ext) (void)hipEventRecord(h->ev[2 * h->ev_used + 1], st);
+      h->ev_kind[h->ev_used] = kind; h->ev_used++;
+    }
   }
 };
 }  // namespace
@@ -3453,9 +3466,13 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 }
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
-  Timed t(h, st, 0);
-  ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const bool dj = h->hc.diagJ != 0;
+#if defined(TOLG_K2_OLD) || defined(TOLG_K2_V4) || defined(TOLG_K2_V5)
+  Timed t(h, st, 0);
+#else
+  Timed t(h, st, 0, dj && h->prob.kind != TOLG_DYN_PENDULUM3D);  // the third form is one launch: timed through its dispatch
+#endif
+  ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const dim3 grid(P.Bp / 4), blk(64);
 #ifndef TOLG_K2_OLD
   // diagonal inertia blocks and a constant input matrix (every reference script except the pendulum): the third form
@@ -3489,11 +3506,11 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
     }
 #endif
     if (h->hc.grav == 0.0) {
-      if (al) hipLaunchKernelGGL((k_backward3<M, false, true>), grid, blk, 0, st, P, it, ms);
-      else hipLaunchKernelGGL((k_backward3<M, false, false>), grid, blk, 0, st, P, it, ms);
+      if (al) t.launch(k_backward3<M, false, true>, grid, blk, P, it, ms);
+      else t.launch(k_backward3<M, false, false>, grid, blk, P, it, ms);
     } else {
-      if (al) hipLaunchKernelGGL((k_backward3<M, true, true>), grid, blk, 0, st, P, it, ms);
-      else hipLaunchKernelGGL((k_backward3<M, true, false>), grid, blk, 0, st, P, it, ms);
+      if (al) t.launch(k_backward3<M, true, true>, grid, blk, P, it, ms);
+      else t.launch(k_backward3<M, true, false>, grid, blk, P, it, ms);
     }
     LAUNCH_CHECK();
     return 0;
@@ -3599,8 +3616,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
         opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block) {
       // accept-always nonlinear rollout and the re-linearisation of the new trajectory in one launch
       {
-        Timed t(h, st, 1);
-        hipLaunchKernelGGL((k_rollout_lin<M>), dim3((P.Bp + 15) / 16), dim3(256), 0, st, P, it);
+        Timed t(h, st, 1, true);
+        t.launch(k_rollout_lin<M>, dim3((P.Bp + 15) / 16), dim3(256), P, it);
         LAUNCH_CHECK();
         h->rec_closed = 1;  // its records carry no defect field (zero by construction): K2 reads zeros instead
       }
