@@ -201,7 +201,8 @@ int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, double* d_ecc
 
 /* Timing hook for bench.py: HIP-event time (ms) and launch count of the dominant kernel
  * (backward sweep) accumulated since the last call with reset != 0.  Synchronises the recorded
- * events only. */
+ * events only.  Timing is not free: an event pair per launch lengthens an accept-always iteration
+ * (two launches) by ~11 us of 600 on an MI355X -- leave it off where the rate matters (default). */
 int tolg_kernel_time(tolg_handle_t h, int32_t reset, double* ms_backward, double* ms_rollout,
                      double* ms_linearize, int64_t* launches);
 void tolg_enable_timing(tolg_handle_t h, int32_t on);
