@@ -1,3 +1,5 @@
+"""Cost / step-size / gradient / defect histories GPU vs oracle for seeds of tools/parity_fuzz.py.
+    python tools/parity_fuzz_detail.py SEED..."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(),"tools"))
 import numpy as np
