@@ -366,6 +366,14 @@ def run_rank(args, rank, world):
     ident = library_identity(args.allow_lib_override)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     multi = world > 1 or args.rccl_selftest   # every `if multi` below is the multi-rank path
+    # stdout carries ONE JSON line and nothing else.  RCCL prints a version banner with printf when its first communicator
+    # comes up (five lines on this image): in the multi-rank path the process's stdout descriptor is therefore pointed at
+    # stderr for the whole run, and rank 0 writes its line to the descriptor that was stdout.
+    real_stdout = None
+    if multi:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -574,7 +582,11 @@ def run_rank(args, rank, world):
         }
         if not args.no_cpu_baseline and world == 1 and args.workload != "al1024":  # (the oracle's batch driver has no AL terms)
             line["cpu_baseline"] = cpu_baseline(prob, x0_q, x0_xi, us0, args.cpu_seconds, args.mode, args.line_search)
-        print(json.dumps(line), flush=True)
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
