@@ -67,6 +67,9 @@ def test_sgpr_written_by_valu_then_read_by_vector_memory(between, n_findings):
     (["v_add_co_u32_e32 v1, vcc, v2, v3", "v_mov_b32_e32 v9, v8", "s_nop 0", "v_addc_co_u32_e32 v4, vcc, v5, v6, vcc"], 0),
     (["v_readfirstlane_b32 s7, v3", "v_mul_f64 v[4:5], s[6:7], v[0:1]"], 1),
     (["s_mov_b32 s7, s9", "v_mul_f64 v[4:5], s[6:7], v[0:1]"], 0),
+    # (the SGPR pair of v_mad_u64_u32 / v_div_scale is an OUTPUT: a write behind a write is no hazard, a read behind it is)
+    (["v_div_scale_f64 v[4:5], s[8:9], v[0:1], v[0:1], v[2:3]", "v_mad_u64_u32 v[6:7], s[8:9], s4, v1, v[2:3]"], 0),
+    (["v_mad_u64_u32 v[6:7], s[8:9], s4, v1, v[2:3]", "v_cndmask_b32_e64 v7, v1, v2, s[8:9]"], 1),
     # 5: VGPR written by a VALU instruction -> readlane; lane select
     (["v_add_u32_e32 v3, v1, v2", "v_readfirstlane_b32 s7, v3"], 1),
     (["v_add_u32_e32 v3, v1, v2", "s_nop 0", "v_readfirstlane_b32 s7, v3"], 0),
@@ -112,7 +115,7 @@ def test_branch_into_the_window_is_followed_to_its_source():
     assert _dpp_lint.lint(t) == []
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(_dpp_lint.LLVM, "llvm-objdump")), reason="no llvm-objdump")
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and not os.environ.get("ROCM_PATH"), reason="no llvm-objdump")
 def test_in_tree_library_has_no_dpp_hazard():
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
         _build.build_extension()

@@ -78,7 +78,13 @@ def build_extension(force=False, verbose=False, extra_flags=(), lint=True):
         if lint:
             # the hand-written DPP blocks run without hazard nops where the emitted code keeps the distance: check that it does
             from . import _dpp_lint
-            _isa = _dpp_lint.disassemble(tmp)
+            try:
+                _isa = _dpp_lint.disassemble(tmp)
+            except _dpp_lint.LintToolsMissing as e:
+                # a usable library is not thrown away for want of binutils: loud, and the unit test of the lint will fail
+                import warnings
+                warnings.warn("HIP extension built WITHOUT the DPP hazard lint: %s" % e)
+                _isa = ""
             findings = _dpp_lint.lint(_isa) + _dpp_lint.lint_more(_isa)
             if findings:
                 bad = _SO + ".hazard"

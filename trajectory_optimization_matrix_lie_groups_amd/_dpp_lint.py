@@ -41,11 +41,32 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
+class LintToolsMissing(RuntimeError):
+    """llvm-objcopy / clang-offload-bundler / llvm-objdump were not found beside the ROCm install."""
+
+
+def llvm_dir():
+    """Directory of the LLVM binutils of the ROCm install in use: beside the hipcc on PATH, then ROCM_PATH, then /opt/rocm."""
+    import shutil
+    cands = []
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root:
+            cands.append(os.path.join(root, "lib", "llvm", "bin"))
+    for c in cands:
+        if all(os.path.exists(os.path.join(c, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
+            return c
+    raise LintToolsMissing("the hazard lint needs llvm-objcopy, clang-offload-bundler and llvm-objdump (looked in %s); "
+                           "build_extension(lint=False) builds without it" % ", ".join(cands))
+
+
 def disassemble(lib):
+    LLVM = llvm_dir()
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
         subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "null")])
@@ -194,7 +215,8 @@ _DPP_CTRL = ("row_newbcast", "row_shl", "row_shr", "quad_perm", "row_bcast", "ro
 
 
 def _carry_form(op):
-    return "_co_" in op or op.startswith("v_div_scale")
+    # the second operand is an SGPR-pair OUTPUT (carry / scale flag), not a source
+    return "_co_" in op or op.startswith(("v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32"))
 
 
 def lint_more(text):

@@ -388,8 +388,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // one knot of records into LDS slot s (wave-uniform source, 16 bytes per lane and instruction)
   auto dma_from = [&](const char* src, int s) {
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)s * B3_SLOT));
-    if constexpr (NKB == 3) rl_dma16x3(uniform_ptr(src), (unsigned)lane * 16u, dst);
-    else rl_dma16x4(uniform_ptr(src), (unsigned)lane * 16u, dst);
+    if constexpr (NKB == 3) rl_dma16x3_rec(uniform_ptr(src), (unsigned)lane * 16u, dst);
+    else rl_dma16x4_rec(uniform_ptr(src), (unsigned)lane * 16u, dst);
   };
   auto dma_knot = [&](int i, int s) {
     dma_from(reinterpret_cast<const char*>(P.REC + recStride * i) + (size_t)blockIdx.x * blockBytes, s);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     if (act && j < 13) {
       __amdgpu_buffer_rsrc_t rGs = mkbuf(gk, 13 * M * sB);
 #pragma unroll
-      for (int u = 0; u < M; u += 2) bst2(rGs, vG, GOFF(u, 0, M), Kst[u], Kst[u + 1]);
+      for (int u = 0; u < M; u += 2) bst2_gk(rGs, vG, GOFF(u, 0, M), Kst[u], Kst[u + 1]);
     }
   };
 #ifdef TOLG_STAMPS

@@ -30,23 +30,23 @@ enum { EC_DEPTH = 4, EC_RECB = 4096, EC_GKB = 3072, EC_ZP = EC_RECB + EC_GKB, EC
 TOLG_DEV void ec_dma2(const void* sbase, unsigned v0, unsigned v1, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 2\n\t"
-               "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %3" TOLG_POL(TOLG_NT_EC) "\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" TOLG_POL(TOLG_NT_EC) "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sbase), "s"(lds_dst) : "memory");
 }
 TOLG_DEV void ec_dma3(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 2\n\t"
-               "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, %4 offset:2048\n\t"
+               "global_load_lds_dwordx4 %1, %4" TOLG_POL(TOLG_NT_EC) "\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024" TOLG_POL(TOLG_NT_EC) "\n\t"
+               "global_load_lds_dwordx4 %3, %4 offset:2048" TOLG_POL(TOLG_NT_EC) "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(sbase), "s"(lds_dst) : "memory");
 }
 TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3_, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 2\n\t"
-               "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+               "global_load_lds_dwordx4 %1, %5" TOLG_POL(TOLG_NT_EC) "\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024" TOLG_POL(TOLG_NT_EC) "\n\t"
+               "global_load_lds_dwordx4 %3, %5 offset:2048" TOLG_POL(TOLG_NT_EC) "\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072" TOLG_POL(TOLG_NT_EC) "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3_), "s"(sbase), "s"(lds_dst) : "memory");
 }

@@ -64,6 +64,49 @@ typedef __attribute__((address_space(4))) Consts DConsts;
 typedef Consts DConsts;  // the host pass only parses the kernels
 #endif
 
+// Cache policy of the streams that are written once by one launch and read once by the next (VERDICT r3 item 1a;
+// MI355X_MICROARCH.md "nt-weights").  Values: 0 default, 1 nt, 2 sc1, 3 sc0 sc1, 7 sc1 nt (loads also 4..6).  Measured on one box
+// each, three rounds, through tools/ab_libs.sh (profiles/r04_nt_policy_ab_{1,2,3}_*.txt; fused launch / backward sweep in ms, base
+// 0.272 / 0.322):
+//   TOLG_NT_RING   the fused launch's input ring (gains, controls, nominal states; LDS-DMA)   nt: 0.256            -> 1
+//   TOLG_NT_REC    the backward sweep's record ring (LDS-DMA)            nt: sweep 0.320 but the NEXT fused launch 0.305  -> 0
+//   TOLG_NT_GKST   the backward sweep's gain stores                      nt: fused launch 0.261 (the reader gains)        -> 1
+//   TOLG_NT_RECST  lin_knot's record stores     nt: 0.265 alone, sc1 0.280 alone; beside RING = GKST = 1: nt 0.251, sc1 0.241  -> 2
+//   TOLG_NT_CURST  the fused launch's commit of the new trajectory       nt: 0.271 alone; with the four above 0.239       -> 1
+//   TOLG_NT_EC     k_expected_change_ring's record and gain streams (merit search)                                         -> 0
+// The effects do not add (sc1 records alone lose, beside nt gains they win): the table is of combinations, not of knobs.
+// Together: fused launch 0.272 -> 0.239 ms, sweep 0.322 -> 0.327, 1 680 -> 1 775 batch-iterations/s.
+#ifndef TOLG_NT_RING
+#define TOLG_NT_RING 1
+#endif
+#ifndef TOLG_NT_REC
+#define TOLG_NT_REC 0
+#endif
+#ifndef TOLG_NT_EC
+#define TOLG_NT_EC 0
+#endif
+#ifndef TOLG_NT_RECST
+#define TOLG_NT_RECST 2
+#endif
+#ifndef TOLG_NT_GKST
+#define TOLG_NT_GKST 1
+#endif
+#ifndef TOLG_NT_CURST
+#define TOLG_NT_CURST 1
+#endif
+#define TOLG_POL_0 ""
+#define TOLG_POL_1 " nt"
+#define TOLG_POL_2 " sc1"
+#define TOLG_POL_3 " sc0 sc1"
+#define TOLG_POL_4 " sc0 sc1 nt"
+#define TOLG_POL_5 " sc0"
+#define TOLG_POL_6 " sc0 nt"
+#define TOLG_POL_7 " sc1 nt"
+// the same policies as the aux operand of the buffer builtins (gfx940 encoding: sc0 = 1, nt = 2, sc1 = 16)
+#define TOLG_AUX(x) ((x) == 1 ? 2 : (x) == 2 ? 16 : (x) == 3 ? 17 : (x) == 4 ? 19 : (x) == 5 ? 1 : (x) == 6 ? 3 : (x) == 7 ? 18 : 0)
+#define TOLG_POL_CAT(x) TOLG_POL_##x
+#define TOLG_POL(x) TOLG_POL_CAT(x)
+
 struct Params {
   const Consts* c;
   int B, Bp, N, m;
@@ -137,6 +180,30 @@ TOLG_DEV void bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, doubl
 TOLG_DEV void bst2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x0, double x1) {
   f64x2 v = {x0, x1};
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+// a plain or non-temporal global store (the A/B knobs above)
+template <int POL, class T>
+TOLG_DEV void gst(T* p, T v) {
+  if constexpr (POL == 0) *p = v;
+  else if constexpr (POL == 1) __builtin_nontemporal_store(v, p);
+  else {
+    // the other policies have no builtin for a global store: inline asm.  The s_nop 1: a store of more than 8 bytes reads its
+    // data late, a VALU write of those registers needs two wait states behind it, and the compiler does not look in here.
+    static_assert(POL == 2 || POL == 3 || POL == 7, "store policies: 0 default, 1 nt, 2 sc1, 3 sc0 sc1, 7 sc1 nt");
+    if constexpr (sizeof(T) == 16) {
+      if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+      else if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    } else {
+      if constexpr (POL == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+      else if constexpr (POL == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+      else asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+    }
+  }
+}
+TOLG_DEV void bst2_gk(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x0, double x1) {  // K2's gain stores
+  f64x2 v = {x0, x1};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, TOLG_AUX(TOLG_NT_GKST));
 }
 // Knot record: everything K2 (and the line-search rollouts) need from the linearisation.  3x3 blocks are
 // stored column-major (column c at +3c).  The record holds what every model needs (REC_BASE + m fields),
@@ -225,11 +292,11 @@ TOLG_DEV State load_state(const Params& P, const double* __restrict__ s, int i, 
   S.v = v3(s[SIDX(10, i, b)], s[SIDX(11, i, b)], s[SIDX(12, i, b)]);
   return S;
 }
+template <int NT = 0>
 TOLG_DEV void store_state(const Params& P, double* __restrict__ s, int i, int b, const State& S) {
-  s[SIDX(0, i, b)] = S.X.q.x; s[SIDX(1, i, b)] = S.X.q.y; s[SIDX(2, i, b)] = S.X.q.z; s[SIDX(3, i, b)] = S.X.q.w;
-  s[SIDX(4, i, b)] = S.X.t.x; s[SIDX(5, i, b)] = S.X.t.y; s[SIDX(6, i, b)] = S.X.t.z;
-  s[SIDX(7, i, b)] = S.w.x; s[SIDX(8, i, b)] = S.w.y; s[SIDX(9, i, b)] = S.w.z;
-  s[SIDX(10, i, b)] = S.v.x; s[SIDX(11, i, b)] = S.v.y; s[SIDX(12, i, b)] = S.v.z;
+  const double x[13] = {S.X.q.x, S.X.q.y, S.X.q.z, S.X.q.w, S.X.t.x, S.X.t.y, S.X.t.z, S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
+#pragma unroll
+  for (int c = 0; c < 13; c++) gst<NT>(&s[SIDX(c, i, b)], x[c]);
 }
 
 // fd_euler (traopt_dynamics.py:763-787 SE3, :1373-1401 Drone, :1049-1077 RigidBody):
@@ -514,13 +581,14 @@ TOLG_DEV void a22_get(const Params& P, const Consts& C, int i, int b, double (&a
 template <int F0, int N>
 TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
   constexpr int H = F0 & 1;  // an odd first field goes alone
-  if constexpr (H) P.REC[RIDX(i, F0, b)] = v[0];
+  constexpr int NT = TOLG_NT_RECST;
+  if constexpr (H) gst<NT>(&P.REC[RIDX(i, F0, b)], v[0]);
 #pragma unroll
   for (int k = H; k + 1 < N; k += 2) {
     f64x2 w = {v[k], v[k + 1]};
-    *reinterpret_cast<f64x2*>(&P.REC[RIDX(i, F0 + k, b)]) = w;
+    gst<NT>(reinterpret_cast<f64x2*>(&P.REC[RIDX(i, F0 + k, b)]), w);
   }
-  if constexpr (((N - H) & 1) != 0) P.REC[RIDX(i, F0 + N - 1, b)] = v[N - 1];
+  if constexpr (((N - H) & 1) != 0) gst<NT>(&P.REC[RIDX(i, F0 + N - 1, b)], v[N - 1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2041,36 +2109,39 @@ struct RlIn {
   enum { GSZ = 13 * (M / 2) * 64, GAINS = 4 * GSZ, STATE = 13 * 128, CTRL = M * 128, SLOT = GAINS + STATE + CTRL,
          NDMA = (GAINS + 1023) / 1024 + 2 + 1 };  // LDS-DMA instructions per knot
 };
-// one 16-byte-per-lane LDS-DMA: lane l copies 16 bytes from gsrc (its own address) to LDS byte address lds_dst + 16 l.
+#define TOLG_DEF_DMA(SUF, POL)                                                                                                   \
+  TOLG_DEV void rl_dma16##SUF(const void* gsrc, unsigned lds_dst) {                                                              \
+    unsigned keep;                                                                                                               \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" POL "\n\ts_mov_b32 m0, %0"    \
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");                                                            \
+  }                                                                                                                              \
+  TOLG_DEV void rl_dma16x4##SUF(const void* sbase, unsigned voff, unsigned lds_dst) {                                            \
+    unsigned keep;                                                                                                               \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"                                                          \
+                 "global_load_lds_dwordx4 %1, %2" POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"                 \
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" POL "\n\t"     \
+                 "s_mov_b32 m0, %0"                                                                                              \
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");                                                \
+  }                                                                                                                              \
+  TOLG_DEV void rl_dma16x3##SUF(const void* sbase, unsigned voff, unsigned lds_dst) {                                            \
+    unsigned keep;                                                                                                               \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"                                                          \
+                 "global_load_lds_dwordx4 %1, %2" POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"                 \
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t"                                                         \
+                 "s_mov_b32 m0, %0"                                                                                              \
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");                                                \
+  }
+// rl_dma16: one 16-byte-per-lane LDS-DMA, lane l copies 16 bytes from gsrc (its own address) to LDS byte address lds_dst + 16 l.
 // In asm, so that the compiler keeps no vmcnt bookkeeping for it (it would drain the DMA queue before every LDS poll);
 // M0, the DMA's LDS base, is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5).
-TOLG_DEV void rl_dma16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// four consecutive KB with one M0 setting: the instruction offset moves both the global and the LDS address.  base is
-// wave-uniform (SGPR pair), voff the lane's byte offset.  The s_nop 2: base may have been written by a v_readfirstlane
-// directly in front of the statement (uniform_ptr), and a VALU write of an SGPR must be five wait states ahead of the
-// vector-memory instruction that reads it -- the compiler pads its own code, not inline asm
-// (tools/dpp_hazard_lint.py, second rule, found k_rollout_lin's bursts at 3-4).  (M0 handling is a quarter of an LDS-DMA's issue time:
+// rl_dma16x4 / x3: four / three consecutive KB with one M0 setting: the instruction offset moves both the global and the LDS
+// address.  base is wave-uniform (SGPR pair), voff the lane's byte offset.  The s_nop 2: base may have been written by a
+// v_readfirstlane directly in front of the statement (uniform_ptr), and a VALU write of an SGPR must be five wait states ahead
+// of the vector-memory instruction that reads it -- the compiler pads its own code, not inline asm (tools/dpp_hazard_lint.py,
+// second rule, found k_rollout_lin's bursts at 3-4).  (M0 handling is a quarter of an LDS-DMA's issue time:
 // tools/lds_dma_microbench.hip)
-TOLG_DEV void rl_dma16x4(const void* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-TOLG_DEV void rl_dma16x3(const void* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-               "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
+TOLG_DEF_DMA(, TOLG_POL(TOLG_NT_RING))       // the fused launch's input ring
+TOLG_DEF_DMA(_rec, TOLG_POL(TOLG_NT_REC))    // the backward sweep's record ring
 TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in a form the "s" constraint accepts
   const unsigned long long a = reinterpret_cast<unsigned long long>(p);
   return reinterpret_cast<const void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
@@ -2377,9 +2448,9 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 #pragma unroll
         for (int a = 0; a < M; a += 2) { const f64x2 w = pu[(a / 2) * 16]; u[a] = w.x; u[a + 1] = w.y; }
 #pragma unroll
-        for (int a = 0; a < M; a++) P.cur_u[UIDX(a, i, b)] = u[a];
+        for (int a = 0; a < M; a++) gst<TOLG_NT_CURST>(&P.cur_u[UIDX(a, i, b)], u[a]);
       }
-      if (i > 0) store_state(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
+      if (i > 0) store_state<TOLG_NT_CURST>(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
       // the terminal knot (in the last group only) goes separately: see lin_knot's TERM
       double lc = 0.0;
       if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
