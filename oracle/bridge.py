@@ -130,14 +130,15 @@ def fit_batch(prob, x0_q, x0_xi, us_init, mode="ms", max_iter=20, tol_grad=0.0, 
     xs_q = np.zeros((B, N + 1, 4, 4)); xs_xi = np.zeros((B, N + 1, 6)); us = np.zeros((B, N, m))
     J_hist = np.full((B, K), np.nan); grad_hist = np.full((B, K + 1), np.nan); defect_hist = np.full((B, K + 1), np.nan)
     iters = np.zeros(B, np.int32); status = np.zeros(B, np.int32); conv = np.zeros(B, np.int32)
+    mu_hist = np.full((B, K), np.nan)
     used = lib().tolg_oracle_fit_batch(int(mode == "ms"), C.byref(prob.c), C.byref(o), B, _p(x0_q), _p(x0_xi),
                                        _p(us_init), _p(xs_q), _p(xs_xi), _p(us), _p(J_hist), _p(grad_hist),
                                        _p(defect_hist), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip),
-                                       conv.ctypes.data_as(_ip), int(threads or 0))
+                                       conv.ctypes.data_as(_ip), int(threads or 0), _p(mu_hist))
     if used < 0:
         raise RuntimeError("oracle fit_batch failed (singular inertia matrix)")
     return dict(xs_q=xs_q, xs_xi=xs_xi, us=us, J_hist=J_hist, grad_hist=grad_hist, defect_hist=defect_hist,
-                iters=iters, status=status, converged=conv, threads=int(used))
+                iters=iters, status=status, converged=conv, threads=int(used), mu_hist=mu_hist)
 
 
 def lin_backward(prob, xs_q, xs_xi, us, ms=True, mu=1.0, delta=2.0, max_reg=1e10):

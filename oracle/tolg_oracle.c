@@ -710,14 +710,14 @@ typedef struct {
 static void ws_alloc(ws_t *w, int N, int m) {
   w->N = N; w->m = m;
   size_t n = (size_t)N;
-  w->d = calloc(n * 12, 8); w->Fx = calloc(n * 144, 8); w->Fu = calloc(n * 12 * m, 8);
-  w->L = calloc(n + 1, 8); w->Lx = calloc((n + 1) * 12, 8); w->Lu = calloc(n * m, 8);
-  w->Lxx = calloc((n + 1) * 144, 8); w->Luu = calloc(n * m * m, 8);
-  w->k = calloc(n * m, 8); w->K = calloc(n * m * 12, 8);
-  w->Vx = calloc((n + 1) * 12, 8); w->Vxx = calloc((n + 1) * 144, 8);
-  w->xq = calloc((n + 1) * 16, 8); w->xxi = calloc((n + 1) * 6, 8); w->us = calloc(n * m, 8);
-  w->nq = calloc((n + 1) * 16, 8); w->nxi = calloc((n + 1) * 6, 8); w->nus = calloc(n * m, 8);
-  w->xerr = calloc((n + 1) * 12, 8); w->uerr = calloc(n * m, 8);
+  w->d = calloc(n * 12, sizeof(double)); w->Fx = calloc(n * 144, sizeof(double)); w->Fu = calloc(n * 12 * m, sizeof(double));
+  w->L = calloc(n + 1, sizeof(double)); w->Lx = calloc((n + 1) * 12, sizeof(double)); w->Lu = calloc(n * m, sizeof(double));
+  w->Lxx = calloc((n + 1) * 144, sizeof(double)); w->Luu = calloc(n * m * m, sizeof(double));
+  w->k = calloc(n * m, sizeof(double)); w->K = calloc(n * m * 12, sizeof(double));
+  w->Vx = calloc((n + 1) * 12, sizeof(double)); w->Vxx = calloc((n + 1) * 144, sizeof(double));
+  w->xq = calloc((n + 1) * 16, sizeof(double)); w->xxi = calloc((n + 1) * 6, sizeof(double)); w->us = calloc(n * m, sizeof(double));
+  w->nq = calloc((n + 1) * 16, sizeof(double)); w->nxi = calloc((n + 1) * 6, sizeof(double)); w->nus = calloc(n * m, sizeof(double));
+  w->xerr = calloc((n + 1) * 12, sizeof(double)); w->uerr = calloc(n * m, sizeof(double));
 }
 static void ws_free(ws_t *w) {
   free(w->d); free(w->Fx); free(w->Fu); free(w->L); free(w->Lx); free(w->Lu); free(w->Lxx); free(w->Luu);
@@ -1189,7 +1189,8 @@ static int ss_fit_ws(const tolg_problem *p, const tolg_options *o, const double 
 int tolg_oracle_fit_batch(int mode_ms, const tolg_problem *p, const tolg_options *o, int B,
                           const double *x0_q, const double *x0_xi, const double *us_init,
                           double *xs_q, double *xs_xi, double *us, double *J_hist, double *grad_hist,
-                          double *defect_hist, int *iters, int *status, int *converged, int threads) {
+                          double *defect_hist, int *iters, int *status, int *converged, int threads,
+                          double *mu_hist /* [B][max_iter] regularisation after each backward pass, or NULL */) {
   int N = p->N, m = p->m, K = o->max_iter, used = 1, err = 0;
   if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel num_threads(threads)
@@ -1223,6 +1224,8 @@ int tolg_oracle_fit_batch(int mode_ms, const tolg_problem *p, const tolg_options
         ss_fit_ws(p, o, x0_q + 16 * (size_t)b, x0_xi + 6 * (size_t)b, us_init + (size_t)b * N * m,
                   xs_q + (size_t)b * 16 * (N + 1), xs_xi + (size_t)b * 6 * (N + 1), us + (size_t)b * N * m, &h, &c, &w);
       iters[b] = h.n_iters; status[b] = h.status; converged[b] = h.converged;
+      if (mu_hist)
+        for (int k = 0; k < K; k++) mu_hist[(size_t)b * K + k] = (k < h.n_iters) ? h.mu_hist[k] : NAN;
     }
     free(h.alpha_hist); free(h.mu_hist); free(h.J_lin); free(h.trial_J); free(h.n_trials);
     if (ok) { ws_free(&w); dyn_free(&c); }

@@ -80,7 +80,7 @@ def test_dry_run_weak_scaling_and_drone_defaults():
     a = bench.parse_args(["--workload", "drone400"])
     assert (a.batch, a.horizon, a.scaling) == (8192, 400, "strong")
     a = bench.parse_args([])
-    assert (a.batch, a.horizon, a.scaling, a.repeats, a.mode) == (4096, 200, "weak", 10, "ms")
+    assert (a.batch, a.horizon, a.scaling, a.repeats, a.mode) == (4096, 200, "weak", 200, "ms")
     # BASELINE configs 2 and 4 at their stated sizes (secondary lines); the SO3 script runs the SS solver
     a = bench.parse_args(["--workload", "so3"])
     assert (a.batch, a.horizon, a.scaling, a.mode) == (1, 100, "weak", "ss")

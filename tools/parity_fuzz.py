@@ -12,21 +12,29 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import bridge as ob  # noqa: E402  (test infrastructure: the checker)
+from oracle import bridge_ld as obl  # noqa: E402  (its long-double twin: the referee)
 from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR, TrackingProblem, workloads  # noqa: E402
 
-TOL_J = 1e-8     # relative, per iteration (tests/test_gpu_matrix.py holds its hand-conditioned cases to 1e-9; of 400 random
-                 # ones one accept-always drone case reached 1.1e-9)
-TOL_U = 1e-5     # controls at the end of the solve.  (north_star asks for 1e-6 on its workloads; with R drawn down to 1e-6 the cost
-                 # is nearly flat in u: seed 7230 has controls 1.3e-6 apart under costs that agree to 1e-13)
+TOL_J = 1e-9     # relative, per iteration -- or ten times what the fp64 oracle itself is away from its long-double twin at that
+                 # iteration (oracle/tolg_oracle_ld.c: the same statements with 11 more mantissa bits), whichever is larger.  Round 3
+                 # widened this number to 1e-8 after seeds 2352 and 30037; both are problems that amplify the last bit of anything
+                 # (profiles/r04_parity_referee.txt: the fp64 ORACLE is 7e-9 resp. 2.2e-8 from the long-double evaluation there)
+TOL_U = 1e-6     # controls at the end of the solve (north_star's figure) for problems with R >= 1e-4 ...
+TOL_U_FLAT = 1e-5  # ... and for the draws with an input weight below that, where the cost is nearly flat in u (seed 7230: controls
+                 # 1.3e-6 apart under costs that agree to 1e-13); the referee's distance widens both in the same way
+REFEREE = True   # --no-referee: fixed tolerances only
 
 
 LARGE = False    # --large: batches of 500 .. 6 000 (the compacted lists and the thread form of the wide line-search stages,
                  # many workgroups, padded tails), horizons of 40 .. 200
 
 
-def draw(seed):
+NKINDS = 5       # model kinds drawn from: the first campaign (seeds 1000 .. 6999) drew among the first three, the second among four
+
+
+def draw(seed, nkinds=None):
     rng = np.random.default_rng(seed)
-    kind = ["se3", "rigidbody", "drone", "so3", "pendulum"][rng.integers(5)]
+    kind = ["se3", "rigidbody", "drone", "so3", "pendulum"][rng.integers(nkinds or NKINDS)]
     diag = bool(rng.integers(4) > 0)
     mode = ["ms", "ss"][rng.integers(2)]
     line_search = bool(rng.integers(2)) if mode == "ms" else False
@@ -87,8 +95,8 @@ def draw(seed):
     return dict(kind=kind, diag=diag, mode=mode, line_search=line_search, rollout=rollout, B=B, N=N, K=K), prob, x0_q, x0_xi, us0
 
 
-def one(seed):
-    cfg, prob, x0_q, x0_xi, us0 = draw(seed)
+def one(seed, nkinds=None):
+    cfg, prob, x0_q, x0_xi, us0 = draw(seed, nkinds)
     K, B = cfg["K"], cfg["B"]
     if isinstance(prob, tuple):
         prob, op = prob
@@ -97,23 +105,75 @@ def one(seed):
     solver = BatchedTrackingILQR(prob, B)
     r = solver.fit_batch(x0_q, x0_xi, us0, mode=cfg["mode"], n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
                          line_search=cfg["line_search"], rollout=cfg["rollout"])
-    o = ob.fit_batch(op, x0_q, x0_xi, us0, mode=cfg["mode"], max_iter=K, line_search=cfg["line_search"], rollout=cfg["rollout"])
+    kw = dict(mode=cfg["mode"], max_iter=K, line_search=cfg["line_search"], rollout=cfg["rollout"])
+    o = ob.fit_batch(op, x0_q, x0_xi, us0, **kw)
     it, st, Jg, us = r.iters.cpu().numpy().copy(), r.status.cpu().numpy().copy(), r.J_hist.cpu().numpy(), r.us.cpu().numpy().copy()
     o["iters"], o["status"] = o["iters"].copy(), o["status"].copy()
+    # the referee: the oracle's statements in long double.  nf[b, k] = how far the fp64 oracle has drifted from it by iteration k
+    # (running maximum) -- the accuracy fp64 HAS on this trajectory; a trajectory on which the two take different decisions
+    # (iteration counts, statuses) has no noise floor beyond that point: `forked`
+    ref = obl.fit_batch(op, x0_q, x0_xi, us0, **kw) if REFEREE else None
     notes, worst_j, worst_u, stats = [], 0.0, 0.0, {}
     Ag = r.alpha_hist.cpu().numpy() if (r.alpha_hist is not None and (cfg["line_search"] or cfg["mode"] == "ss")) else None
+    Mg = r.mu_hist.cpu().numpy() if getattr(r, "mu_hist", None) is not None else None
+    Xg = r.xs_xi.cpu().numpy()
+    searching = cfg["line_search"] or cfg["mode"] == "ss"
+    tol_u0 = TOL_U if float(np.diag(prob.R)[: (4 if cfg["kind"] == "drone" else 3 if cfg["kind"] in ("so3", "pendulum") else 6)].min()) >= 1e-4 else TOL_U_FLAT
     for b in range(B):
         n = min(int(it[b]), int(o["iters"][b]))
         stats[int(o["status"][b])] = stats.get(int(o["status"][b]), 0) + 1
-        # a trajectory that has left the regime in which two fp64 implementations can agree: overflowing costs, or a
-        # gradient beyond 1e8 (an unstable rollout amplifies the last bits of its input: the three disagreements of the first
-        # 300-case run, J off by 7e-9 .. 6e-8 relative, all had gradient norms of 5e8 .. 8e11 and the max-regularisation status)
         jo = o["J_hist"][b, :max(n, 1)]
-        exploding = n > 1 and np.isfinite(jo).all() and (jo[1:] > 1e3 * np.abs(jo[:-1])).any()   # accept-always divergence on its way
-        wild = exploding or (not np.isfinite(o["J_hist"][b, :max(n, 1)]).all()) or np.abs(o["J_hist"][b, :max(n, 1)]).max() > 1e30 or \
-               (np.nanmax(np.abs(o["grad_hist"][b, :max(n, 1)])) > 1e8)
-        if wild:
-            stats["wild"] = stats.get("wild", 0) + 1
+        finite = bool(np.isfinite(jo).all() and np.abs(jo).max() < 1e30)
+        nf = np.zeros(max(n, 1))
+        ref_agrees_gpu = ref_agrees_oracle = False
+        if ref is not None:
+            nr = min(n, int(ref["iters"][b]))
+            with np.errstate(all="ignore"):
+                d = np.abs((o["J_hist"][b, :nr].astype(obl.LD) - ref["J_hist"][b, :nr]) / ref["J_hist"][b, :nr]).astype(float)
+            d = np.where(np.isfinite(d), d, np.inf)
+            nf[:nr] = np.maximum.accumulate(d) if nr else 0.0
+            nf[nr:] = np.inf   # the referee has stopped: the fp64 oracle is on its own from here
+            ref_agrees_gpu = int(ref["iters"][b]) == int(it[b]) and int(ref["status"][b]) == int(st[b])
+            ref_agrees_oracle = int(ref["iters"][b]) == int(o["iters"][b]) and int(ref["status"][b]) == int(o["status"][b])
+        else:
+            # without the referee: round 3's classification of what cannot be compared (overflowing costs, a cost that grows a
+            # thousandfold in one accept-always iteration, gradients beyond 1e8)
+            exploding = n > 1 and finite and (jo[1:] > 1e3 * np.abs(jo[:-1])).any()
+            if exploding or not finite or (np.nanmax(np.abs(o["grad_hist"][b, :max(n, 1)])) > 1e8):
+                nf[:] = np.inf
+        if not finite:
+            stats["nonfinite"] = stats.get("nonfinite", 0) + 1
+        # ILL-CONDITIONED trajectories: a backward sweep whose regularisation ran away (mu >= 1e20 on either side: the sweep gave
+        # up on a positive definite Q_uu at max_reg = 1e10 and the schedule of traopt_controller.py:2977-2995, carried from knot to
+        # knot, kept multiplying -- every such case of the campaigns ended between 1e30 and 1e100), a cost that grows a
+        # thousandfold in one accept-always iteration, or overflow.  Such a sweep solves INDEFINITE systems whose entries span
+        # thirty and more orders of magnitude; the GPU's gains agree with the oracle's to ~1e-5 there (tools/_dbg_maxreg.py,
+        # profiles/r04_parity_referee.txt) and what a line search then does with them differs.  Costs are compared up to the first
+        # such iteration (with the referee's tolerance); exit codes and iteration counts are still compared and COUNTED
+        # (`ill_exit_differs`), and fail the case only if one side reports a clean run (status 0) where the other reports a
+        # failure.  (A max-regularisation exit that stays near 1e10 -- seed 30003 -- is NOT in this class: compared in full.)
+        mu_o = o["mu_hist"][b, :max(n, 1)]
+        mu_g = Mg[b, :max(n, 1)] if Mg is not None else mu_o
+        bad_k = [k for k in range(n) if not np.isfinite(jo[k]) or abs(jo[k]) > 1e30 or mu_o[k] >= 1e20 or mu_g[k] >= 1e20
+                 or o["grad_hist"][b, k] > 1e8   # (linearised a thousand rad/s away from anything: twists of 1e2 .. 1e12, seed 20144)
+                 or (k > 0 and not searching and jo[k] > 1e3 * abs(jo[k - 1]))]
+        # a rollout that has left the number range (twists beyond 1e6 rad/s on either side: seeds 20172, 20223 blow up in their
+        # FIRST accept-always iteration, which no ratio of successive costs shows)
+        diverged = float(np.abs(o["xs_xi"][b]).max()) > 1e6 or not np.isfinite(o["xs_xi"][b]).all() or float(np.nanmax(np.abs(Xg[b]))) > 1e6 \
+            or not np.isfinite(Xg[b]).all()
+        if diverged and not bad_k:
+            bad_k = [0]
+        if bad_k or not finite:
+            stats["ill"] = stats.get("ill", 0) + 1
+            n_cmp = min(bad_k) if bad_k else 0
+            if it[b] != o["iters"][b] or st[b] != o["status"][b]:
+                stats["ill_exit_differs"] = stats.get("ill_exit_differs", 0) + 1
+                if (st[b] == 0) != (o["status"][b] == 0):
+                    notes.append("b%d (ill-conditioned) status %d/%d: one side clean, the other failed" % (b, st[b], o["status"][b]))
+            if n_cmp:
+                with np.errstate(all="ignore"):
+                    e = np.abs(Jg[b, :n_cmp] - jo[:n_cmp]) / np.abs(jo[:n_cmp]) / np.maximum(TOL_J, 10.0 * nf[:n_cmp])
+                worst_j = max(worst_j, float(np.nanmax(np.where(np.isfinite(e), e, 0.0))) * TOL_J)
             continue
         if n and cfg["mode"] == "ms" and cfg["line_search"]:
             # The merit function is J + w |d| with w re-derived every iteration from the expected change over |d|
@@ -122,44 +182,73 @@ def one(seed):
             # is that noise's reciprocal, and which step size passes is decided by the noise: seed 7061, two SO(3) members
             # 1e-3 apart after agreeing to 1e-14 for seven iterations.  The comparison ends at the first such disagreement.
             a, c = Jg[b, :n], o["J_hist"][b, :n]
-            off = np.nonzero(np.abs(a - c) > TOL_J * np.abs(c).max())[0]
+            with np.errstate(all="ignore"):
+                off = np.nonzero(np.abs(a - c) > np.maximum(TOL_J, 10.0 * nf[:n]) * np.abs(c).max())[0]
             if off.size and o["defect_hist"][b, off[0]] < 1e-12:
                 stats["merit_noise"] = stats.get("merit_noise", 0) + 1
                 n = int(off[0])
                 it[b] = o["iters"][b] = n   # (nothing behind it is comparable, the way the searches end included)
                 st[b] = o["status"][b] = 0
                 us[b] = o["us"][b]
+                ref_agrees_gpu = ref_agrees_oracle = False
         if n:
             a, c = Jg[b, :n], o["J_hist"][b, :n]
-            e = np.abs(a - c) / np.abs(c).max()
+            with np.errstate(all="ignore"):
+                e = np.abs(a - c) / np.abs(c)
+            e = np.where(np.isfinite(e), e, np.where(np.isfinite(a) == np.isfinite(c), 0.0, np.inf))   # same finiteness class
             if Ag is not None:
                 # a search that ends up accepting steps of 1e-7 and below is deciding its Armijo test within a hundred
                 # rounding errors of the cost: the two sides may then take DIFFERENT step sizes of that order (seed 2030:
                 # costs 0.5 alpha apart behind two accepted steps of 7.7e-9) -- allow the sum of such steps so far
                 tiny = np.cumsum(np.where(Ag[b, :n] < 1e-6, Ag[b, :n], 0.0))
                 e = np.maximum(e - 10.0 * tiny, 0.0)
-            worst_j = max(worst_j, e.max())
+            # measured in units of the tolerance at that iteration: max(TOL_J, ten times the oracle's own distance from the referee)
+            with np.errstate(all="ignore"):
+                ee = e / np.maximum(TOL_J, 10.0 * nf[:n])
+            ee = np.where(np.isnan(ee), 0.0, ee)
+            if np.isinf(nf[:n]).any():
+                stats["beyond_referee"] = stats.get("beyond_referee", 0) + 1
+            worst_j = max(worst_j, float(ee.max()) * TOL_J)
         if it[b] != o["iters"][b] or st[b] != o["status"][b]:
-            # a search that has converged to rounding level ends on a coin flip (tests/test_gpu_matrix.py): the side that
-            # goes on does so without moving the cost
+            # the exit code and the iteration count are compared for EVERY trajectory, diverging ones included.  Accepted:
+            # (1) the long-double referee takes the GPU's decision (the fp64 oracle's was the rounding one: seed 30003);
+            # (2) the referee takes neither side's (three evaluations, three outcomes: decided by rounding);
+            # (3) a search that has converged to rounding level ends on a coin flip (tests/test_gpu_matrix.py): the side that
+            #     goes on does so without moving the cost
             longer = Jg[b, : it[b]] if it[b] > o["iters"][b] else o["J_hist"][b, : o["iters"][b]]
             tail = longer[max(n - 1, 0):]
             searching = cfg["line_search"] or cfg["mode"] == "ss"
-            if searching and np.isfinite(tail).all() and np.ptp(tail) <= 1e-10 * abs(tail[0]):   # (1e-11 in the hand-conditioned matrix test; 3.5e-11 seen in 47 000 random trajectories)
+            if ref is not None and ref_agrees_gpu:
+                stats["oracle_rounding"] = stats.get("oracle_rounding", 0) + 1
+            elif ref is not None and not ref_agrees_oracle:
+                stats["three_way"] = stats.get("three_way", 0) + 1
+            elif searching and len(tail) and np.isfinite(tail).all() and np.ptp(tail) <= 1e-10 * abs(tail[0]):   # (1e-11 in the hand-conditioned matrix test; 3.5e-11 seen in 47 000 random trajectories)
                 stats["coin"] = stats.get("coin", 0) + 1
             else:
                 notes.append("b%d iters %d/%d status %d/%d tail ptp %.1e" % (b, it[b], o["iters"][b], st[b], o["status"][b],
                                                                              np.ptp(tail) / abs(tail[0]) if len(tail) else -1))
         elif st[b] == 0 and np.isfinite(o["us"][b]).all():
             slack = 10.0 * float(np.where(Ag[b, :n] < 1e-6, Ag[b, :n], 0.0).sum()) if Ag is not None else 0.0
-            worst_u = max(worst_u, max(np.abs(us[b] - o["us"][b]).max() / max(1.0, np.abs(o["us"][b]).max()) - slack, 0.0))
+            scale = max(1.0, np.abs(o["us"][b]).max())
+            eu = np.abs(us[b] - o["us"][b]).max() / scale
+            nfu = 0.0
+            if ref is not None and ref_agrees_oracle:
+                nfu = float(np.abs(o["us"][b].astype(obl.LD) - ref["us"][b]).max()) / scale
+            elif ref is not None:
+                nfu = np.inf
+            worst_u = max(worst_u, max(eu - slack, 0.0) / max(tol_u0, 10.0 * nfu) * TOL_U)
     return cfg, worst_j, worst_u, notes, stats
 
 
 def main():
-    global LARGE
-    args = [a for a in sys.argv[1:] if a != "--large"]
-    LARGE = "--large" in sys.argv[1:]
+    global LARGE, REFEREE, NKINDS
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    LARGE = "--large" in flags
+    REFEREE = "--no-referee" not in flags
+    for f in flags:
+        if f.startswith("--kinds="):
+            NKINDS = int(f.split("=")[1])
     n = int(args[0]) if len(args) > 0 else 100
     s0 = int(args[1]) if len(args) > 1 else 1000
     bad = 0
@@ -173,7 +262,7 @@ def main():
             bad += 1
         print("%s seed %d %s  J %.1e  u %.1e  %s %s" % ("DIFF" if flag else "ok  ", seed, cfg, wj, wu, "; ".join(notes[:6]),
                                                           ("(+%d more)" % (len(notes) - 6)) if len(notes) > 6 else ""), flush=True)
-    print("%d of %d cases differ; over all trajectories: oracle statuses / wild (skipped) / coin flips at rounding level: %s"
+    print("%d of %d cases differ (J and u in units of their tolerance x 1e-9 / 1e-6); over all trajectories: oracle statuses / classes: %s"
           % (bad, n, status_total))
     return 1 if bad else 0
 

@@ -4040,3 +4040,16 @@ extern "C" int tolg_selftest_series(int32_t n, const double* d_args, double* d_o
   LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef TOLG_TIER_COUNT
+// diagnostic builds only (tools/tier_share.py): read / reset the series-tier counters of tolg_lie.h.  Not in include/tolg.h.
+extern "C" int tolg_debug_tier_counts(unsigned long long* out6, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return TOLG_E_LAUNCH;
+  if (out6 && hipMemcpyFromSymbol(out6, HIP_SYMBOL(tolg::g_tier), 6 * sizeof(unsigned long long)) != hipSuccess) return TOLG_E_LAUNCH;
+  if (reset) {
+    const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tolg::g_tier), z, sizeof z) != hipSuccess) return TOLG_E_LAUNCH;
+  }
+  return 0;
+}
+#endif

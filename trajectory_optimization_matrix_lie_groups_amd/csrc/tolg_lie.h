@@ -212,10 +212,28 @@ TOLG_DEV void se3_log(Pose X, V3& w, V3& v) {
 // ------------------------------------------------------------------------------------------------
 TOLG_DEV bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 struct SeriesGate { bool any_long, any_fb; };
+#ifdef TOLG_TIER_COUNT
+// Diagnostic build (tools/tier_share.py, never the product): how many lanes / gates (= waves at one rollout step or linearised
+// knot) fall into each tier -- [0..2] lanes short / long / closed form, [3..5] gates by the most expensive tier they execute.
+__device__ unsigned long long g_tier[6];
+#endif
 TOLG_DEV SeriesGate series_gate(bool small, bool dom) {
   SeriesGate g;
   g.any_long = any_lane(!small);
   g.any_fb = any_lane(!dom);
+#ifdef TOLG_TIER_COUNT
+  {
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true), bs = __builtin_amdgcn_ballot_w64(small),
+                             bd = __builtin_amdgcn_ballot_w64(dom);
+    const unsigned me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (ex != 0 && me == (unsigned)__builtin_ctzll(ex)) {  // the lowest active lane reports for the wave
+      atomicAdd(&g_tier[0], (unsigned long long)__builtin_popcountll(bs & bd));
+      atomicAdd(&g_tier[1], (unsigned long long)__builtin_popcountll(ex & ~bs & bd));
+      atomicAdd(&g_tier[2], (unsigned long long)__builtin_popcountll(ex & ~bd));
+      atomicAdd(&g_tier[g.any_fb ? 5 : g.any_long ? 4 : 3], 1ull);
+    }
+  }
+#endif
   return g;
 }
 // Per-lane predicates of the four argument kinds.  A gate built from log_small / log_dom of y = |q_v|^2 also
