@@ -66,10 +66,16 @@ def parse_args(argv=None):
                          "regime; reported as config.fresh_solve, never as `value`); 0 = off")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (weak) or in all (strong); default 4096 (se3) / 8192 (drone400)")
     ap.add_argument("--horizon", type=int, default=None, help="default 200 (se3) / 400 (drone400)")
-    ap.add_argument("--workload", choices=["se3", "drone400", "so3", "al1024"], default="se3",
+    ap.add_argument("--workload", choices=["se3", "drone400", "so3", "al1024", "pendulum"], default="se3",
                     help="se3: the metric's workload; drone400 / so3 / al1024: BASELINE configs 5 / 2 / 4 at their stated sizes "
                          "(secondary lines; so3 defaults to the SS solver its script uses, al1024 times inner MS iterations with "
-                         "the AL terms of the first outer iteration attached)")
+                         "the AL terms of the first outer iteration attached; pendulum: Pendulum3dDyanmics swing-up, 80 knots -- the "
+                         "model with a state-dependent input matrix, on the general backward sweep)")
+    ap.add_argument("--rollout", choices=["nonlinear", "linear"], default="nonlinear",
+                    help="linear: the reference constructors' own default (traopt_controller.py:1837-1838, :2359-2363), which every "
+                         "script overrides; secondary line")
+    ap.add_argument("--inertia", choices=["diag", "dense"], default="diag",
+                    help="dense: full 3x3 inertia blocks (the general backward sweep k_backward instead of k_backward3); secondary line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default weak (se3) / strong (drone400)")
     ap.add_argument("--mode", choices=["ms", "ss"], default=None, help="default ms (ss for --workload so3)")
     ap.add_argument("--line-search", action="store_true")
@@ -90,9 +96,9 @@ def parse_args(argv=None):
                     help="(tests) with --dry-run: this rank exits 3 before the rendezvous")
     a = ap.parse_args(argv)
     if a.batch is None:
-        a.batch = {"se3": 4096, "drone400": 8192, "so3": 1, "al1024": 1024}[a.workload]
+        a.batch = {"se3": 4096, "drone400": 8192, "so3": 1, "al1024": 1024, "pendulum": 4096}[a.workload]
     if a.horizon is None:
-        a.horizon = {"se3": 200, "drone400": 400, "so3": 100, "al1024": 200}[a.workload]
+        a.horizon = {"se3": 200, "drone400": 400, "so3": 100, "al1024": 200, "pendulum": 80}[a.workload]
     if a.scaling is None:
         a.scaling = "strong" if a.workload == "drone400" else "weak"
     if a.mode is None:
@@ -320,14 +326,17 @@ def host_cpu_share():
     return n
 
 
-def cpu_baseline(prob, x0_q, x0_xi, us0, seconds, mode="ms", line_search=False):
+def cpu_baseline(prob, x0_q, x0_xi, us0, seconds, mode="ms", line_search=False, rollout="nonlinear"):
     """The CPU oracle (oracle/tolg_oracle.c: the parity-checked port of the reference algorithm) on this
     host's cores: OpenMP over trajectories, one workspace per thread.  Bounded sample of the same workload:
     all B trajectories, as many iterations as fit in about `seconds`; thread count and iteration count come
     from short calibration probes, so the sample stays bounded whatever the host's real CPU share is."""
     from oracle import bridge as ob
-    op = ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
+    op = ob.OracleProblem(prob.kind, prob.J, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref,
+                          pend_mass=getattr(prob, "pend_mass", 0.0), pend_length=getattr(prob, "pend_length", 0.0))
     kw = dict(mode=mode, line_search=line_search) if line_search else dict(mode=mode)
+    if rollout != "nonlinear":
+        kw["rollout"] = rollout
     B = x0_q.shape[0]
     # one thread, 4 trajectories x 20 iterations: the single-core rate (what one reference fit corresponds to)
     nb1, it1 = min(4, B), 20
@@ -451,7 +460,12 @@ def run_rank(args, rank, world):
     drone = lambda B_, N=400, seed=workloads.SEED: workloads.drone_tracking(B_, N=N, seed=seed, R_scale=args.r_scale or 1e-3)
     se3 = (lambda B_, N=200, seed=workloads.SEED: workloads.se3_tracking(B_, N=N, seed=seed, R_scale=args.r_scale)) if args.r_scale \
         else workloads.se3_tracking
-    make = {"se3": se3, "drone400": drone, "so3": workloads.so3_tracking,
+    def pend(B_, N=80, seed=workloads.SEED):
+        p_, q_, xi_, u_ = workloads.pendulum_swingup(B_, seed=seed)
+        if N != p_.N:
+            raise SystemExit("bench.py: the stored pendulum swing-up path has %d knots" % p_.N)
+        return p_, q_, xi_, u_
+    make = {"se3": se3, "drone400": drone, "so3": workloads.so3_tracking, "pendulum": pend,
             "al1024": lambda B_, N=200, seed=workloads.SEED: workloads.al_tracking(B_, N=N, seed=seed)[:4]}[args.workload]
     if args.scaling == "weak":
         # each rank owns an independent shard of the weak-scaled batch: different seeded perturbations
@@ -462,6 +476,17 @@ def run_rank(args, rank, world):
         lo, hi = sharding.shard_bounds(B_global, world, rank)
         x0_q, x0_xi, us0 = gq[lo:hi], gxi[lo:hi], gus[lo:hi]
     m = us0.shape[2]
+    if args.inertia == "dense":
+        # the same problem with full inertia blocks (a rotated body frame's inertia): J = blkdiag(Ib + A A^T, Jv) keeps the
+        # structure the reference's G assumes; the backward sweep then reads I + H dt from the records (k_backward)
+        import numpy as np
+        from trajectory_optimization_matrix_lie_groups_amd import TrackingProblem
+        Jd = np.array(prob.J, dtype=float).copy()
+        A_ = np.array([[0.10, -0.05, 0.02], [0.03, 0.12, -0.04], [-0.02, 0.06, 0.09]])
+        Jd[:3, :3] += A_ @ A_.T
+        if prob.kind == "se3":
+            Jd[3:, 3:] += 0.5 * (A_ @ A_.T)
+        prob = TrackingProblem(prob.kind, Jd, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
     solver = BatchedTrackingILQR(prob, B, device=dev)
     x0_q_d = torch.as_tensor(x0_q, device=dev); x0_xi_d = torch.as_tensor(x0_xi, device=dev)
     us0_d = torch.as_tensor(us0, device=dev)
@@ -481,7 +506,8 @@ def run_rank(args, rank, world):
     headline = args.mode == "ms" and not args.line_search
     regions, kern = [], []
     fresh, fresh_active = [], None
-    begin_kw = dict(mode=args.mode, tol_grad_norm=0.0, tol_d_norm=0.0, schedule=args.schedule, line_search=args.line_search)
+    begin_kw = dict(mode=args.mode, tol_grad_norm=0.0, tol_d_norm=0.0, schedule=args.schedule, line_search=args.line_search,
+                    rollout=args.rollout)
 
     # Per-kernel durations need an event pair per launch, and timing costs the step 11 us of its 600 (tools/event_cost.py:
     # 607 against 596 us at 4096 x 200 with the pair attached to the dispatch; 614 with marker packets around it).  So the regions alternate: even ones carry the
@@ -582,18 +608,23 @@ def run_rank(args, rank, world):
                                ("k_linearize", kl)), key=lambda kv: kv[1])
         dom_gbs = alg_bytes / (t_dom * 1e-3) / 1e9 if t_dom > 0 else None
         step_gbs = alg_bytes / (ms_step * 1e-3) / 1e9
-        std_cfg = args.workload == "se3" and B == 4096 and N == 200 and headline and args.schedule == "auto" and not args.r_scale
+        std_cfg = (args.workload == "se3" and B == 4096 and N == 200 and headline and args.schedule == "auto" and not args.r_scale
+                   and args.rollout == "nonlinear" and args.inertia == "diag")
         traffic, traffic_src = measured_traffic(dominant) if std_cfg else (None, None)
         measured_gbs = traffic / (t_dom * 1e-3) / 1e9 if (traffic and t_dom > 0) else None
         what = {"se3": "SE3 exact tracking", "drone400": "drone racing tracking (BASELINE config 5; R = 1e-3 I)",
                 "so3": "SO3 exact tracking (BASELINE config 2)",
+                "pendulum": "Pendulum3dDyanmics swing-up tracking (state-dependent input matrix)",
                 "al1024": "SE3 AL-DDP MS with input box constraints, inner iterations of the first outer iteration "
                           "(BASELINE config 4)"}[args.workload]
         algo = ("MS-iLQR" if args.mode == "ms" else "SS-iLQR") + (
-            " (line_search=%s, rollout=nonlinear)" % ("True" if args.line_search else "False") if args.mode == "ms" else " (13-alpha backtracking)")
+            " (line_search=%s, rollout=%s)" % ("True" if args.line_search else "False", args.rollout) if args.mode == "ms"
+            else " (13-alpha backtracking%s)" % (", rollout=linear" if args.rollout == "linear" else ""))
+        if args.inertia == "dense":
+            what += " [dense inertia blocks]"
         if args.r_scale:
             what += " [R = %g I]" % args.r_scale
-        metric = METRIC if (args.workload == "se3" and headline and B == 4096 and N == 200 and not args.r_scale) else (
+        metric = METRIC if std_cfg else (
             "DDP iterations/sec at batch x horizon = %d x %d (%s, %s)" % (B_global if args.scaling == "strong" else B, N, what, algo))
         line = {
             "metric": metric,
@@ -605,7 +636,7 @@ def run_rank(args, rank, world):
                            ("one global batch of %d split over %d GPU(s): %d on rank 0" % (B_global, world, B))) +
                            " x N=%d knots" % N,
                        "batch_per_gpu": B, "horizon": N, "global_batch": B_global, "schedule": args.schedule,
-                       "mode": args.mode, "line_search": bool(args.line_search),
+                       "mode": args.mode, "line_search": bool(args.line_search), "rollout": args.rollout, "inertia": args.inertia,
                        "value_counts": "one unit = every trajectory of a %d-trajectory batch advanced by one iteration"
                                        % (B if args.scaling == "weak" else B_global),
                        "trajectory_iterations_per_s": value * (B if args.scaling == "weak" else B_global),
@@ -654,7 +685,7 @@ def run_rank(args, rank, world):
                                  "(DESIGN.md §5)"},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload != "al1024":  # (the oracle's batch driver has no AL terms)
-            line["cpu_baseline"] = cpu_baseline(prob, x0_q, x0_xi, us0, args.cpu_seconds, args.mode, args.line_search)
+            line["cpu_baseline"] = cpu_baseline(prob, x0_q, x0_xi, us0, args.cpu_seconds, args.mode, args.line_search, args.rollout)
         if real_stdout is not None:
             sys.stdout.flush()
             os.write(real_stdout, (json.dumps(line) + "\n").encode())

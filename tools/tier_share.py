@@ -6,13 +6,13 @@ headline's first timed region slower because of clocks or because of WORK?)  Nee
 Every Exp / Log / Jacobian-coefficient evaluation of tolg_lie.h runs under a SeriesGate: short series (per-step rotation
 < 0.2 rad, deviation from the nominal < 0.06 rad), long series, or the closed forms for the lanes outside the series' domain;
 a wave pays for the most expensive tier any of its lanes needs.  The counters are per lane and per gate (wave x step); the
-table prints both shares per window of iterations of ONE fresh solve, with the time per iteration of the same windows
-(the diagnostic build's atomics cost a few per cent; the times are for comparing windows, not a benchmark)."""
+table prints both shares per window of iterations of ONE fresh solve.  (No times: every gate of the diagnostic build adds to
+six global counters with atomics, which serialises the chip -- 5.9 ms per iteration instead of 0.57; the time per window of the
+product build is bench.py's `fresh_solve` series.)"""
 import argparse
 import ctypes as C
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -46,20 +46,18 @@ def main():
         lib.tolg_debug_tier_counts(out, 1)
         rows = []
         for lo, hi in zip(edges[:-1], edges[1:]):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
             solver.solve_iterate(hi - lo)
             torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / (hi - lo) * 1e3
+            dt = 0.0
             lib.tolg_debug_tier_counts(out, 1)
             c = np.array(list(out), dtype=float)
             rows.append((lo, hi, dt, c[:3] / max(c[:3].sum(), 1), c[3:] / max(c[3:].sum(), 1)))
         res = solver.solve_end()
     print("# %s%s, %d x %d, one fresh solve (second pass, GPU warm); shares of lanes / of gates (wave x step) per tier"
           % (a.mode, " + line search" if a.line_search else "", a.batch, a.horizon))
-    print("# iterations     ms/iteration   lanes: short  long  closed-form   gates: short  long  closed-form")
+    print("# iterations     lanes: short  long  closed-form   gates: short  long  closed-form")
     for lo, hi, dt, l, g in rows:
-        print("  %4d..%-4d      %8.4f          %.4f %.4f %.4f            %.4f %.4f %.4f" % (lo, hi - 1, dt, l[0], l[1], l[2], g[0], g[1], g[2]))
+        print("  %4d..%-4d       %.4f %.4f %.4f            %.4f %.4f %.4f" % (lo, hi - 1, l[0], l[1], l[2], g[0], g[1], g[2]))
     print("# active at the end: %.4f" % float((res.iters == edges[-1]).double().mean().item()))
 
 

@@ -51,7 +51,17 @@ TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, 
                : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3_), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int M, bool GRAV>
+// STORE (round 4, rollout = 'linear'): the recursion also WRITES what it computes -- e_i and du_i = k_i + K_i e_i at alpha = 1 --
+// to P.ED, [knot][trajectory][32] doubles (e in 0..11, du in 16..16+m; one 512-byte run per wave, array and knot).  The linear
+// rollout of the reference (traopt_controller.py:2720-2737 MS, :2065-2071 SS) is this affine recursion with alpha k_i and
+// alpha d_i in place of k_i and d_i and e_0 = 0, so e_i(alpha) = alpha e_i(1): EVERY candidate of a line search is
+// x_i (+) alpha e_i, u_i + alpha du_i -- one sweep instead of one sequential rollout per step size (k_ls_eval_affine,
+// k_affine_commit in tolg_kernels.hip).  Trajectories handed back (a rotation deviation of 3 rad or more somewhere: Log(Exp(v))
+// is no longer v there, and the wrapped recursion is not linear in alpha) keep the statement-form rollouts.
+// The stores are two global_store_dwordx2 per step, issued by every lane of every wave that runs the loop (lanes without a
+// row write zeros into the padding), in asm so that they take a KNOWN place in the in-order memory queue: the counted waits
+// on the DMA ring add them up.
+template <int M, bool GRAV, bool STORE = false>
 __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
@@ -183,6 +193,9 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   double e = 0.0, a1 = 0.0, a2 = 0.0;
   bool bad = false;
+  // (STORE) this lane's slot of knot 0 in P.ED and the distance to the next knot's
+  double* ed_run = STORE ? P.ED + ((size_t)b * 32 + j) : nullptr;
+  const size_t edStride = (size_t)P.Bp * 32;
   // e^T l_xx e, this lane's row: pose rows against the record's block, twist rows against 2 W2 (or 2 P2)
   auto quad_state = [&](const double (&Lr)[6], const double (&Wr)[6]) {
     double t = bcast<0>(e) * Lr[0];
@@ -199,10 +212,12 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     const char* sl = lds + SLOT * EC_SLOT;
     auto ld = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(sl + off); };
     // knot i was requested EC_DEPTH - 1 steps ago; behind it at most the requests of knots i + 1 .. i + EC_DEPTH - 2
+    // (STORE: behind knot i's request also sit the two stores of each of the last EC_DEPTH - 1 steps)
+    constexpr int NST = STORE ? 2 * (EC_DEPTH - 1) : 0;
     if (i + EC_DEPTH - 2 <= N - 1) {
-      if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7) : "memory");
-      else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5) : "memory");
+      if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7 + NST) : "memory");
+      else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6 + NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5 + NST) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last steps: fewer requests behind this knot's than the count assumes
     }
@@ -231,6 +246,10 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     du = fma(bcast<6>(e), Kr[6], du); du = fma(bcast<7>(e), Kr[7], du); du = fma(bcast<8>(e), Kr[8], du);
     du = fma(bcast<9>(e), Kr[9], du); du = fma(bcast<10>(e), Kr[10], du); du = fma(bcast<11>(e), Kr[11], du);
     du *= mU;
+    if constexpr (STORE) {
+      asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:128" :: "v"(ed_run), "v"(e), "v"(du) : "memory");
+      ed_run += edStride;
+    }
     // _expected_cost_change, knot i (:2760-2765; l_ux = 0 for the tracking costs)
     a1 = fma(lx, e, a1);
     a1 = fma(lu, du, a1);
@@ -281,6 +300,7 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   if (i < N) { step(i, std::integral_constant<int, 0>()); i++; }
   if (i < N) { step(i, std::integral_constant<int, 1>()); i++; }
   if (i < N) { step(i, std::integral_constant<int, 2>()); i++; }
+  if constexpr (STORE) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(ed_run), "v"(e) : "memory");  // e_N
   // terminal knot (:2766-2768): l_x(N) and the pose block of l_xx(N) by plain loads -- issued here, behind the sweep, so
   // that the compiler's own vmcnt bookkeeping never meets the DMA queue inside the knot loop
   {

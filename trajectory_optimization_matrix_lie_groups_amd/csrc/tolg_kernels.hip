@@ -138,6 +138,9 @@ struct Params {
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
   int* k2_redo;        // [Bp/4]   groups of four whose sweep k_backward4 handed to k_backward3 (tolg_backward4.h)
   int* ec_redo;        // [Bp]     trajectories k_expected_change_ring hands to k_expected_change (tolg_expected_change.h)
+  double* ED;          // [N+1][Bp][32] rollout = 'linear': deviation e_i (0..11) and control step du_i (16..16+m) of the alpha = 1
+                       //          linear rollout, written by k_expected_change_ring<.., STORE>
+  int affine, pad3;    // this solve takes its linear-rollout candidates from ED (every trajectory with ec_redo == 0)
   // line search, round 3 form: the stages roll out only (quad rollouts over a compacted list of the undecided
   // trajectories), costs and defects of the candidates are evaluated in parallel over the knots
   int* ls_list;        // [2][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
@@ -1993,6 +1996,7 @@ __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, 
   const bool live = b < P.Bp;
   if (!live) b = P.Bp - 1;
   if (!P.active[b]) return;  // quad-uniform
+  if (LINEAR && P.affine && !P.ec_redo[b]) return;  // (quad-uniform) its linear rollout comes from the affine recursion
   const bool writer = live && q == 0;  // one lane of a live quad stores
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
   State Sn;  // new trajectory, knot i
@@ -2517,14 +2521,16 @@ enum { LS_QUAD_MAX = 20000 };
 TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots) { return list < 0 || P.ls_count[list] * nslots <= LS_QUAD_MAX; }
 
 // stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738)
-template <int M>
+// FAST: the series forms of tolg_lie.h (what the rollouts and the linearisation use) in place of the closed-form Log
+template <int M, bool FAST = false>
 TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const State& S, const double (&u)[M], bool term) {
   const double* r = P.ref + 13 * (size_t)i;
   Pose Xr;
   Xr.q.x = r[0]; Xr.q.y = r[1]; Xr.q.z = r[2]; Xr.q.w = r[3];
   Xr.t = v3(r[4], r[5], r[6]);
   V3 ew, ev;
-  se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+  if constexpr (FAST) se3_log_fast(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
+  else se3_log(se3_compose(S.X, se3_inverse(Xr)), ew, ev);
   const bool so3 = so3_family(C.kind);  // the SO3 terminal cost is weighted with Q (App. C-Q3)
   const double* W1 = (term && !so3) ? C.P1 : C.W1;
   const double* W2 = (term && !so3) ? C.P2 : C.W2;
@@ -2567,6 +2573,7 @@ __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nsl
   if (b >= P.Bp || slot >= nslots) return;
   if (ls_quad_form(P, list, nslots)) return;  // the quad form's turn
   if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  if (LINEAR && P.affine && !P.ec_redo[b]) return;  // its candidates come from the affine recursion (k_ls_eval_affine)
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai);
   const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
@@ -2688,6 +2695,7 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
     b = live ? quad : P.Bp - 1;
     if (!P.active[b] || P.ls_accept[b] >= 0) return;  // quad-uniform
   }
+  if (LINEAR && P.affine && !P.ec_redo[b]) return;  // (quad-uniform) its candidates come from the affine recursion
   const bool writer = live && q == 0;
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai);
@@ -2749,6 +2757,7 @@ __global__ __launch_bounds__(256) void k_ls_eval(Params P, int nslots, int direc
     if (n * nslots > LS_QUAD_MAX || e >= n) return;
     b = P.ls_list[(size_t)list * P.Bp + e];
   } else if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  if (P.affine && !P.ec_redo[b]) return;  // k_ls_eval_affine's
   const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp;
   const double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
   const double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
@@ -2767,17 +2776,20 @@ __global__ __launch_bounds__(256) void k_ls_eval(Params P, int nslots, int direc
     }
   }
 }
+// affine_part: the sums of k_ls_eval_affine's trajectories (every list length: there is no thread form for them); otherwise
+// the stored candidates' -- in a solve that runs the affine path, only the trajectories that path handed back
 template <bool MS>
-__global__ void k_ls_sum(Params P, int a0, int nslots, int list) {
+__global__ void k_ls_sum(Params P, int a0, int nslots, int list, int affine_part) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = t % P.Bp, slot = t / P.Bp, N = P.N;
   if (slot >= nslots) return;
   int b = e;
   if (list >= 0) {
     const int n = P.ls_count[list];
-    if (n * nslots > LS_QUAD_MAX || e >= n) return;
+    if ((!affine_part && n * nslots > LS_QUAD_MAX) || e >= n) return;
     b = P.ls_list[(size_t)list * P.Bp + e];
   } else if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  if (affine_part ? (P.ec_redo[b] != 0) : (P.affine && !P.ec_redo[b])) return;
   const double* c = P.LSC + (size_t)slot * (N + 1) * P.Bp + e;
   const double* d = P.LSD + (size_t)slot * N * P.Bp + e;
   double J = 0, d2 = 0;
@@ -2793,6 +2805,92 @@ __global__ void k_ls_sum(Params P, int a0, int nslots, int list) {
   J += c[(size_t)N * P.Bp];
   P.Jtrial[(size_t)b * 20 + a0 + slot] = J;
   P.dtrial[(size_t)b * 20 + a0 + slot] = sqrt(d2);
+}
+
+// ---- rollout = 'linear' without rollouts (round 4).  k_expected_change_ring<.., STORE> has left e_i and du_i of the alpha = 1
+// linear rollout in P.ED; the candidate of step size alpha is x_i (+) alpha e_i, u_i + alpha du_i (note at that kernel).  One
+// thread per (trajectory, knot, alpha) builds it where it is needed: k_ls_eval_affine for the stage costs and (MS) squared
+// defects of a line-search stage -- k_ls_eval's outputs at k_ls_eval's places, so k_ls_sum / k_ls_select go on unchanged --,
+// k_affine_commit for the accepted one (or, `all`, the alpha = 1 candidate of an accept-always iteration).  Trajectories the
+// recursion handed back (ec_redo) are left to the statement-form kernels, which in such a solve touch nothing else.
+template <int M>
+TOLG_DEV void affine_candidate(const Params& P, int i, int b, double alpha, State& S, double (&u)[M]) {
+  const State So = load_state(P, P.cur, i, b);
+  const f64x2* ed = reinterpret_cast<const f64x2*>(P.ED + ((size_t)i * P.Bp + b) * 32);
+  if (i == 0) {
+    S = So;  // xs_new[0] = xs[0] (:2666)
+  } else {
+    // x_i (+) alpha e_i: the right-plus of :2730-2733 (q_next_mnf + tangent), re-normalised like every group operation here
+    const f64x2 e0 = ed[0], e1 = ed[1], e2 = ed[2], e3 = ed[3], e4 = ed[4], e5 = ed[5];
+    const Pose D = se3_exp_fast(alpha * v3(e0.x, e0.y, e1.x), alpha * v3(e1.y, e2.x, e2.y));
+    S.X = se3_project(se3_compose(So.X, D));
+    S.w = So.w + alpha * v3(e3.x, e3.y, e4.x);
+    S.v = So.v + alpha * v3(e4.y, e5.x, e5.y);
+  }
+  if (i < P.N) {
+#pragma unroll
+    for (int a = 0; a < M; a += 2) {
+      const f64x2 d2 = ed[8 + a / 2];
+      u[a] = P.cur_u[UIDX(a, i, b)] + alpha * d2.x;
+      u[a + 1] = P.cur_u[UIDX(a + 1, i, b)] + alpha * d2.y;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < M; a++) u[a] = 0.0;
+  }
+}
+template <int M, bool MS>
+__global__ __launch_bounds__(256) void k_ls_eval_affine(Params P, int a0, int nslots, int list) {
+  const Consts& C = *P.c;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int slot = blockIdx.y, N = P.N;
+  if (slot >= nslots || t >= (size_t)(N + 1) * P.Bp) return;
+  const int e = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  int b = e;
+  if (list >= 0) {
+    if (e >= P.ls_count[list]) return;
+    b = P.ls_list[(size_t)list * P.Bp + e];
+  } else if (!P.active[b] || P.ls_accept[b] >= 0) return;
+  if (P.ec_redo[b]) return;
+  const double alpha = ls_alpha_k(a0 + slot);
+  State S;
+  double u[M];
+  affine_candidate<M>(P, i, b, alpha, S, u);
+  P.LSC[((size_t)slot * (N + 1) + i) * P.Bp + e] = knot_cost<M, true>(P, C, i, b, S, u, i == N);
+  if constexpr (MS) {
+    if (i < N) {
+      State Nx;
+      double un[M];
+      affine_candidate<M>(P, i + 1, b, alpha, Nx, un);
+      const DynK DK = dynk_load(C);
+      const State Fn = dyn_f_k<M, Consts, 0>(DK, C, S, u);
+      V3 dw, dv;
+      se3_log_fast(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+      const V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
+      P.LSD[((size_t)slot * N + i) * P.Bp + e] = dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
+    }
+  }
+}
+template <int M>
+__global__ __launch_bounds__(256) void k_affine_commit(Params P, int a0, int all) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  if (!P.active[b] || P.ec_redo[b]) return;
+  double alpha = 1.0;
+  if (!all) {
+    const int s = P.ls_slot[b];
+    if (s < 0) return;
+    alpha = ls_alpha_k(a0 + s);
+  }
+  State S;
+  double u[M];
+  affine_candidate<M>(P, i, b, alpha, S, u);
+  store_state(P, P.cand, i, b, S);
+  if (i < P.N) {
+#pragma unroll
+    for (int a = 0; a < M; a++) P.cand_u[UIDX(a, i, b)] = u[a];
+  }
 }
 
 // MS merit search preparation (traopt_controller.py:2550-2557): linear alpha = 1 rollout (not stored),
@@ -2931,6 +3029,7 @@ __global__ void k_ls_copy(Params P, int list, int nslots) {
   const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
   const int s = P.ls_slot[b];
   if (s < 0 || !P.active[b]) return;
+  if (P.affine && !P.ec_redo[b]) return;  // k_affine_commit's
   const int e = (list >= 0 && ls_quad_form(P, list, nslots)) ? P.ls_pos[(size_t)list * P.Bp + b] : b;
   const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)P.m * P.Bp;
   const double* sx = P.slot_x + (size_t)s * stStride * (P.N + 1);
@@ -3276,7 +3375,9 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* ls_pos = c.take<int>(2 * B);
   double* LSC = c.take<double>((size_t)NSLOT * (N + 1) * B);
   double* LSD = c.take<double>((size_t)NSLOT * N * B);
+  double* ED = c.take<double>((N + 1) * 32 * B);
   if (P) {
+    P->ED = ED; P->affine = 0; P->pad3 = 0;
     P->k2_redo = k2_redo;
     P->ec_redo = ec_redo;
     P->ls_list = ls_list; P->ls_count = ls_count; P->ls_pos = ls_pos; P->LSC = LSC; P->LSD = LSD;
@@ -3520,6 +3621,7 @@ static Params params_for(tolg_handle_s* h, int B) {
   P.fLUU = REC_LU + P.m + (grav ? 4 : 0);
   P.fA22 = a22 ? P.fLUU + (P.al_lb != nullptr ? P.m : 0) : -1;
   P.pad2 = 0;
+  P.affine = 0;
   return P;
 }
 
@@ -3619,6 +3721,21 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
   LAUNCH_CHECK();
   return 0;
 }
+// rollout = 'linear', models of the third backward form: the alpha = 1 linear rollout as an affine recursion, e_i and du_i
+// left in P.ED (tolg_expected_change.h, STORE), plus -- what the kernel is named after -- the expected cost change and the
+// defect weight of the merit search.  The trajectories it hands back get their expected change from the statement form.
+template <int M>
+static int run_affine_dev(tolg_handle_s* h, const Params& P, hipStream_t st, bool merit) {
+  Timed t(h, st, 1);
+  if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true, true>), dim3(P.Bp / 4), dim3(64), 0, st, P);
+  else hipLaunchKernelGGL((k_expected_change_ring<M, false, true>), dim3(P.Bp / 4), dim3(64), 0, st, P);
+  LAUNCH_CHECK();
+  if (merit) {
+    hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
 // One stage of the speculative line search: alphas a0 .. a0 + n - 1 of every still-undecided trajectory at once.
 // stage = 0, 1, 2 ...: stage 0 takes the undecided trajectories from the flags (all active ones), stage s > 0 from the
 // list select s - 1 compacted (lists alternate: select s fills list s & 1 while this stage's kernels read the other).
@@ -3661,8 +3778,14 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
     const size_t nn = (size_t)(P.N + 1) * P.Bp;
     hipLaunchKernelGGL((k_ls_eval<M, MS>), dim3((unsigned)((nn + 255) / 256), n), dim3(256), 0, st, P, n, direct, list_in);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_ls_sum<MS>), dim3((unsigned)(((size_t)P.Bp * n + 63) / 64)), dim3(64), 0, st, P, a0, n, list_in);
+    hipLaunchKernelGGL((k_ls_sum<MS>), dim3((unsigned)(((size_t)P.Bp * n + 63) / 64)), dim3(64), 0, st, P, a0, n, list_in, 0);
     LAUNCH_CHECK();
+    if (P.affine) {  // the candidates that come from the affine recursion: built where they are evaluated
+      hipLaunchKernelGGL((k_ls_eval_affine<M, MS>), dim3((unsigned)((nn + 255) / 256), n), dim3(256), 0, st, P, a0, n, list_in);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL((k_ls_sum<MS>), dim3((unsigned)(((size_t)P.Bp * n + 63) / 64)), dim3(64), 0, st, P, a0, n, list_in, 1);
+      LAUNCH_CHECK();
+    }
   }
   if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
   hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n, list_out);
@@ -3670,6 +3793,11 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   if (!direct) {
     size_t nn = (size_t)(P.N + 1) * P.Bp;
     hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, list_in, n);
+    LAUNCH_CHECK();
+  }
+  if (P.affine) {
+    size_t nn = (size_t)(P.N + 1) * P.Bp;
+    hipLaunchKernelGGL(k_affine_commit<M>, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, a0, 0);
     LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, list_out ^ 1);
@@ -3694,7 +3822,25 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       }
       continue;  // the fused launch also sums the costs and does the bookkeeping of k_reduce
     } else if (!opt->line_search) {
+      if (P.affine) {  // x^ = x (+) e, u^ = u + du from the affine recursion; the statement form for what it hands back
+        if ((rc = run_affine_dev<M>(h, P, st, false))) return rc;
+        Timed t(h, st, 1);
+        const size_t nn = (size_t)(P.N + 1) * P.Bp;
+        hipLaunchKernelGGL(k_affine_commit<M>, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, 0, 1);
+        LAUNCH_CHECK();
+      }
       if ((rc = run_rollout_ms<M>(h, P, st, 1.0, opt->rollout_linear))) return rc;
+    } else if (P.affine) {
+      hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
+      LAUNCH_CHECK();
+      if ((rc = run_affine_dev<M>(h, P, st, true))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, 1))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, 1))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, 1))) return rc;
+      if (!so3_family(h->prob.kind))
+        if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, 1))) return rc;
+      hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+      LAUNCH_CHECK();
     } else {
       hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it == 0 ? 1 : 0);
       LAUNCH_CHECK();
@@ -3750,6 +3896,7 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     if ((rc = run_backward<M>(h, P, st, it, 0))) return rc;
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
+    if (P.affine && (rc = run_affine_dev<M>(h, P, st, false))) return rc;
     if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
     // (1 + 4 + 8 like the merit search was measured: 405 -> 339 it/s on iterations 3..23 of the benchmark solve, whose
     // searches end at the 6th to 10th step size -- tools/ls_alpha_histogram.py; it would pay from iteration ~45 on, where
@@ -3777,6 +3924,9 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
   P.J_hist = d_J_hist; P.grad_hist = d_grad_hist; P.defect_hist = d_defect_hist; P.alpha_hist = d_alpha_hist;
   P.mu_hist = d_mu_hist; P.max_iter = opt->max_iter; P.tol_grad = opt->tol_grad; P.tol_defect = opt->tol_defect;
   P.max_reg = opt->max_reg;
+  // rollout = 'linear' as an affine recursion (k_expected_change_ring<.., STORE>): the models of the third backward form;
+  // TOLG_SCHED_SPLIT keeps the statement-form rollouts for every trajectory (the A/B partner in the tests)
+  P.affine = (opt->rollout_linear && P.fA22 < 0 && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT) ? 1 : 0;
   size_t n = (size_t)(P.N + 1) * P.Bp;
   hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, ms);
   LAUNCH_CHECK();
