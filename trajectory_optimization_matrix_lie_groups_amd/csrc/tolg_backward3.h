@@ -24,10 +24,14 @@
 //    runs beside the rank-m update.  The update term is symmetric up to the rounding of its fused multiply-adds, so
 //    what has to be symmetrised (the reference's V <- (V + V^T)/2, :3004) is Q_xx = l_xx + F_x^T V F_x alone -- and
 //    that is known long before the factorisation ends: its LDS transpose round trip, which sat on the critical path
-//    of every knot in k_backward, passes behind the factorisation here.  It cannot be dropped: the antisymmetric
-//    part of V is an unstable mode of this form of the recursion (S' = F_x^T S F_x + (B K)^T S (B K): the cross
-//    terms that make the closed loop contract are symmetric and never see it); left alone it grew from 1e-16 to
-//    1e-8 over 130-200 knots (tests/test_gpu_fused.py, test_gpu_parity.py caught it).
+//    of every knot in k_backward, passes behind the factorisation here.  It cannot be dropped altogether: the
+//    antisymmetric part of V is an unstable mode of this form of the recursion (S' = F_x^T S F_x + (B K)^T S (B K): the
+//    cross terms that make the closed loop contract are symmetric and never see it); left alone it grew from 1e-16 to
+//    1e-8 over 130-200 knots (tests/test_gpu_fused.py, test_gpu_parity.py caught it).  It does not have to happen at
+//    every knot either (the reference symmetrises every knot, :3004): since late round 3 every TOLG_K3_SYMP-th knot
+//    (4; note at `sym_now` below) -- between two symmetrisations the mode grows by ~1.1 per knot on the benchmark
+//    workload (4 at worst), i.e. to < 3e-14 of |V| before it is removed; tests/test_gpu_symmetrisation.py bounds the
+//    difference to a build that symmetrises every knot on a long-horizon, low-R drone problem.
 template <int M>
 __host__ __device__ constexpr int urow(int u) { return (u < 3 || M == 6) ? 6 + u : 11; }  // state row driven by input u
 
@@ -238,9 +242,6 @@ enum { B3_DATA = 5120, B3_ZBYTES = 256,
        B3_KC = B3_DUMP + 12 * B3_TRS * 8, B3_LDS = B3_KC + 16 * 16 * 8 };
 
 // AL: augmented-Lagrangian solve (the records carry the l_uu diagonal; decides the record size with M and GRAV).
-#ifndef TOLG_K3_X
-#define TOLG_K3_X 0
-#endif
 template <int M, bool GRAV, bool AL>
 __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
@@ -443,10 +444,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // The records of knot i were requested two steps ago; the memory queue retires in order, so "everything but
     // the last step's gain stores and record request" is a counted wait.  (Step 0 is preceded by a step that
     // requested nothing.)
-#if TOLG_K3_X != 1  // (TOLG_K3_X: timing experiments that drop one piece of the step; results are wrong by construction)
     if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M / 2 + NKB) : "memory");
-#endif
     // (One VALU instruction stands in front of most of these reads: the lane's address comes back from an AGPR.  With
     // absolute addresses and the slot as an instruction immediate the v_add of the slot-relative form went, the AGPR
     // read stayed: no gain, not kept.)
@@ -501,18 +500,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     STAMP(1)
 #endif
     gk_run -= gStride;
-#if TOLG_K3_X == 5 || TOLG_K3_X == 6  // gains only from the first sweep of a solve (later sweeps: no stores)
-    if (i < N - 1 && it <= 0) store_gains(gk_run);
-#elif TOLG_K3_X != 2
     if (i < N - 1) store_gains(gk_run);
-#endif
 #ifdef TOLG_STAMPS2
     STAMP(2)
 #endif
     rec_run -= recStrideB;
-#if TOLG_K3_X != 3 && TOLG_K3_X != 6
     if (i >= 2) dma_from(rec_run, SLOT);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef TOLG_STAMPS2
     STAMP(2)
@@ -578,9 +571,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #define TOLG_K3_SYMP 4
 #endif
     static_assert(TOLG_K3_SYMP >= 1 && (TOLG_K3_SYMP & (TOLG_K3_SYMP - 1)) == 0, "symmetrisation period: a power of two");
-#if TOLG_K3_X == 4 || TOLG_K3_X == 6
-    constexpr bool sym_now = false;
-#elif TOLG_K3_SYMP <= 2
+#if TOLG_K3_SYMP <= 2
     constexpr bool sym_now = TOLG_K3_SYMP == 1 || SLOT == 0;
 #else
     const bool sym_now = SLOT == 0 && (i & (TOLG_K3_SYMP - 1)) == 0;

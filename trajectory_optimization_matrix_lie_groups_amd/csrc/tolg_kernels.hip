@@ -1904,11 +1904,7 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
   } else {
     __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
     double lin[12], d[12];
-#ifdef TOLG_AS4_LINEAR  // (experiment: the round-2 failure -- F_u's constants through address space 4 inside a knot loop)
-    fx_apply<M>(P, C, i, b, e, du, lin);
-#else
     fx_apply<M>(P, *P.c, i, b, e, du, lin);
-#endif
 #pragma unroll
     for (int a = 0; a < 12; a++) d[a] = alpha * bld(rR, REC_VR(b), FOFF(REC_D + a));
     State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
@@ -1983,11 +1979,7 @@ template <int M, bool LINEAR, bool ALPHA1, int PK = 0>
 __global__ __launch_bounds__(64) void k_rollout(Params P, double alpha, int i0, int i1) {
   // knots [i0, i1): a rollout can be issued in segments so that the re-linearisation of finished
   // knots (K1, on a second stream) overlaps the remaining sequential sweep
-#ifdef TOLG_AS4_LINEAR
-  typedef DConsts CT;
-#else
   typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
-#endif
   const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int b = t >> 2;
@@ -2152,12 +2144,6 @@ TOLG_DEV const void* uniform_ptr(const void* p) {  // a wave-uniform address, in
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
 }
 #include "tolg_backward3.h"
-#ifdef TOLG_K2_V5
-#include "tolg_backward5.h"
-#endif
-#ifdef TOLG_K2_V4
-#include "tolg_backward4.h"
-#endif
 
 template <int M>
 TOLG_DEV void rl_in_load(const char* slot, int tt, int q, RollIn<M>& R) {
@@ -2270,9 +2256,6 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     // (old/4 - h) / RL_NH + 1 of them.  (The pose wave writes slot i + 1 only after it has seen step i - 1
     // published, which this check precedes.)
     auto slot_free = [&](int i) -> bool {
-#ifdef TOLG_EXP_NOLIN
-      return true;
-#endif
       if ((i & 7) != 0 || i + 8 < RL_RING) return true;
       const int go = (i + 8 - RL_RING) / 4;
 #pragma unroll
@@ -2416,9 +2399,6 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     return;
   }
   // ---------------- linearisation helpers: pass g covers knots 4g .. 4g+3 (lane / 16) of the 16 trajectories (lane % 16)
-#ifdef TOLG_EXP_NOLIN
-  return;
-#endif
   const int h = wave - 2, kk = lane >> 4, tt = lane & 15, b = b0 + tt;
   const bool mine = b < P.Bp && P.active[b < P.Bp ? b : 0] != 0;
   const int ngroups = (N + 1 + 3) / 4;
@@ -2669,11 +2649,7 @@ template <int M, bool MS, bool LINEAR, int PK>
 __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots, int direct, int list) {
   // constants as in K3 (k_rollout): the address-space-4 view for the nonlinear step, the generic pointer for the linear
   // one (fx_apply reads F_u's constants in the knot loop: note at DConsts)
-#ifdef TOLG_AS4_LINEAR
-  typedef DConsts CT;
-#else
   typedef typename std::conditional<LINEAR, Consts, DConsts>::type CT;
-#endif
   const CT& C = *(const CT*)P.c;
   const int t = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   const int quad = t >> 2, q = t & 3;
@@ -3640,44 +3616,13 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   const bool dj = h->hc.diagJ != 0;
-#if defined(TOLG_K2_OLD) || defined(TOLG_K2_V4) || defined(TOLG_K2_V5)
-  Timed t(h, st, 0);
-#else
   Timed t(h, st, 0, dj && h->prob.kind != TOLG_DYN_PENDULUM3D);  // the third form is one launch: timed through its dispatch
-#endif
   ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const dim3 grid(P.Bp / 4), blk(64);
-#ifndef TOLG_K2_OLD
   // diagonal inertia blocks and a constant input matrix (every reference script except the pendulum): the third form
   // of the sweep (tolg_backward3.h).  Dense inertia and the pendulum keep k_backward.
   if (dj && h->prob.kind != TOLG_DYN_PENDULUM3D) {
     const bool al = P.al_lb != nullptr;
-#ifdef TOLG_K2_V5
-    // (experiment, off by default: measured slower -- tolg_backward5.h)  no gravity block, no AL terms, m = 6: the
-    // wave-pair form, with k_backward3 behind it for the groups it hands back
-    if constexpr (M == 6) {
-      if (h->hc.grav == 0.0 && !al && P.N >= 8) {
-        hipLaunchKernelGGL((k_backward5<6>), dim3((P.Bp / 4 + 1) / 2), dim3(256), 0, st, P, it, ms);  // two groups per workgroup
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_backward3<6, false, false>), grid, blk, 0, st, P, it, ms | 4);
-        LAUNCH_CHECK();
-        return 0;
-      }
-    }
-#endif
-#ifdef TOLG_K2_V4
-    // (experiment, off by default: measured slower -- tolg_backward4.h)  no gravity block, no AL terms, m = 6: the
-    // half-column form, two waves per SIMD, with k_backward3 behind it for the groups it hands back
-    if constexpr (M == 6) {
-      if (h->hc.grav == 0.0 && !al) {
-        hipLaunchKernelGGL((k_backward4<6, false, false>), grid, dim3(128), 0, st, P, it, ms);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_backward3<6, false, false>), grid, blk, 0, st, P, it, ms | 4);
-        LAUNCH_CHECK();
-        return 0;
-      }
-    }
-#endif
     if (h->hc.grav == 0.0) {
       if (al) t.launch(k_backward3<M, false, true>, grid, blk, P, it, ms);
       else t.launch(k_backward3<M, false, false>, grid, blk, P, it, ms);
@@ -3688,7 +3633,6 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
     LAUNCH_CHECK();
     return 0;
   }
-#endif
   if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
     if (dj) hipLaunchKernelGGL((k_backward<6, true, true, true>), grid, blk, 0, st, P, it, ms);
     else hipLaunchKernelGGL((k_backward<6, true, true, false>), grid, blk, 0, st, P, it, ms);
@@ -3846,9 +3790,17 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       LAUNCH_CHECK();
       // the defect weight's linear rollout on a side stream: the first stage's rollout does not need it, its select does
       // (both are 256-wave latency chains; side by side they take the longer one's time, not the sum)
-      if (!h->side) {
-        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return TOLG_E_LAUNCH;
-        for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&h->side_ev[k], hipEventDisableTiming) != hipSuccess) return TOLG_E_LAUNCH;
+      if (!h->side) {  // all or nothing, as for the active-count buffers of tolg_solve_iterate_until
+        hipStream_t sd = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool ok = hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+          for (int k = 0; k < 2; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
+          if (sd) (void)hipStreamDestroy(sd);
+          return TOLG_E_LAUNCH;
+        }
+        h->side_ev[0] = ev[0]; h->side_ev[1] = ev[1]; h->side = sd;
       }
       if (hipEventRecord(h->side_ev[0], st) != hipSuccess || hipStreamWaitEvent(h->side, h->side_ev[0], 0) != hipSuccess) return TOLG_E_LAUNCH;
       if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
@@ -4007,9 +3959,20 @@ extern "C" int tolg_solve_iterate_until(tolg_handle_t h, int32_t n_iter, int32_t
     return 0;
   }
   if (!h->d_cnt) {
-    if (hipMalloc((void**)&h->d_cnt, 2 * sizeof(int)) != hipSuccess) return TOLG_E_LAUNCH;
-    if (hipHostMalloc((void**)&h->h_cnt, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return TOLG_E_LAUNCH;
-    for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&h->cnt_ev[k], hipEventDisableTiming) != hipSuccess) return TOLG_E_LAUNCH;
+    // all or nothing: the handle sees the counters only when every piece exists (a partial set-up left behind by a failed
+    // call would be taken for a complete one by the next call)
+    int *dc = nullptr, *hc = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ok = hipMalloc((void**)&dc, 2 * sizeof(int)) == hipSuccess &&
+              hipHostMalloc((void**)&hc, 2 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      if (dc) (void)hipFree(dc);
+      if (hc) (void)hipHostFree(hc);
+      for (int k = 0; k < 2; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
+      return TOLG_E_LAUNCH;
+    }
+    h->h_cnt = hc; h->cnt_ev[0] = ev[0]; h->cnt_ev[1] = ev[1]; h->d_cnt = dc;
   }
   // Slices of check_every iterations; behind each, the count of trajectories still iterating goes to pinned host
   // memory.  The host looks at the count of the slice BEFORE the one it has just queued, so the device always has a
