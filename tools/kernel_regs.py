@@ -15,9 +15,9 @@ def main():
     pats = sys.argv[1:]
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
-        subprocess.check_call([f"{L.LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", pkg.lib_path(), os.path.join(d, "null")])
-        subprocess.check_call([f"{L.LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--targets={L.TARGET}", f"--output={co}"])
-        notes = subprocess.check_output([f"{L.LLVM}/llvm-readelf", "--notes", co]).decode()
+        subprocess.check_call([f"{L.llvm_dir()}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", pkg.lib_path(), os.path.join(d, "null")])
+        subprocess.check_call([f"{L.llvm_dir()}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--targets={L.TARGET}", f"--output={co}"])
+        notes = subprocess.check_output([f"{L.llvm_dir()}/llvm-readelf", "--notes", co]).decode()
     for e in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
         e = ".agpr_count" + e
         m = re.search(r"\.name:\s+(\S+)", e)

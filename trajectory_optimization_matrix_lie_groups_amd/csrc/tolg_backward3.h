@@ -242,11 +242,20 @@ enum { B3_DATA = 5120, B3_ZBYTES = 256,
        B3_KC = B3_DUMP + 12 * B3_TRS * 8, B3_LDS = B3_KC + 16 * 16 * 8 };
 
 // AL: augmented-Lagrangian solve (the records carry the l_uu diagonal; decides the record size with M and GRAV).
-template <int M, bool GRAV, bool AL>
+// FAST (round 4): the sweep WITHOUT the general path in its kernel.  The common case -- no regularisation left, every pivot
+// positive -- is all the kernel can do; a wave that meets anything else (mu != 0 on entry, a non-positive pivot at some knot)
+// flags its group of four trajectories in P.k2_redo and leaves, and the full kernel (FAST = false), launched behind it with
+// flag bit 2, redoes exactly those groups from the terminal knot: nothing the fast wave wrote survives (gains of the knots it
+// got through are overwritten, mu / delta / gradient are written in the epilogue only).  Why two kernels: with the retry loop,
+// the max-regularisation exit and its pivoted LU compiled in, the kernel needs 395 unified registers (139 of them AGPRs, each
+// use a v_accvgpr copy); without them 254 and no AGPR -- 0.338 -> 0.304 ms at 4096 x 200 on one box (tools/ab_libs.sh;
+// profiles/r04_k2_fast_only_ab.txt), and two waves fit a SIMD at batches beyond 4096.  The first sweep of a solve (mu = 1) goes
+// to the full kernel directly; a sweep with nothing to redo pays one launch of waves that read a flag and leave.
+template <int M, bool GRAV, bool AL, bool FAST = false>
 __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
   // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here
-  // bit 2: fallback behind k_backward4 (tolg_backward4.h): only the groups of four that kernel flagged
+  // bit 2: fallback behind the FAST kernel: only the groups of four that kernel flagged
   if ((flags & 4) && !P.k2_redo[blockIdx.x]) return;
   const int ms = flags & 1;
   const bool closed = (flags & 2) != 0;
@@ -254,11 +263,24 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
   const bool act = P.active[b] != 0;
+  if constexpr (FAST) {
+    // hand the group back at once if any of its trajectories still carries regularisation, or if its last sweep needed the
+    // general path somewhere (P.k2_hint, kept by the full kernel: a group that keeps meeting non-positive pivots -- single
+    // shooting with small input weights does, sweep after sweep -- must not pay for a fast attempt that dies half way
+    // every time; the full kernel clears the hint after a sweep that never left the fast path).  Wave-uniform, and before
+    // anything is requested from memory.
+    const bool back = __any(act && P.mu[b] != 0.0) || P.k2_hint[blockIdx.x] != 0;
+    if (lane == 0) P.k2_redo[blockIdx.x] = back ? 1 : 0;
+    if (back) return;
+  }
   if (!__any(act)) return;
   const int N = P.N;
   // LDS: two record slots (one knot of this wave's four trajectories each, exactly as it lies in REC), a zeroed pad
   // that stands in for structurally-zero fields
-  __shared__ __attribute__((aligned(16))) char lds[B3_LDS];
+  // (FAST fits two waves on a SIMD by its registers; measured at 8192 x 200 that is SLOWER than one at a time -- 0.80 against
+  // 0.66 ms, twice the waves on the same LDS-DMA and DPP paths -- so its LDS request is padded to a quarter of a CU's LDS and
+  // a CU takes four workgroups, one per SIMD, as it does for the full kernel through its registers)
+  __shared__ __attribute__((aligned(16))) char lds[FAST ? (B3_LDS > 34 * 1024 ? B3_LDS : 34 * 1024) : B3_LDS];
   if (lane < B3_ZBYTES / 8) {
     reinterpret_cast<double*>(lds + B3_DATA)[lane] = 0.0;
     reinterpret_cast<double*>(lds + B3_SLOT + B3_DATA)[lane] = 0.0;
@@ -432,6 +454,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_ct0 = st_t;
 #endif
 
+  bool failed = false;  // (FAST) a knot the fast path could not settle: wave-uniform
   // ---- one knot.  SLOT (compile time): the LDS slot that holds knot i; the loop below is unrolled by two.
   auto step = [&](int i, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
@@ -638,7 +661,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #ifdef TOLG_K3_NOFAST
     if (false) {
 #else
-    if (!__any(act && mu != 0.0)) {
+    if (FAST || !__any(act && mu != 0.0)) {
 #endif
       double Y[M], Uf[M], nri[M], dv[M];
 #pragma unroll
@@ -656,7 +679,10 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
         settled = true;
       }
     }
-    if (!settled) {
+    if constexpr (FAST) {
+      if (!settled) { failed = true; return; }  // a non-positive pivot: the full kernel redoes this group (wave-uniform)
+    } else if (!settled) {
+      failed = true;  // (full kernel: "this sweep needed the general path" -> P.k2_hint)
       double Y2[M], U2[M], nr2[M], d2[M];
       for (;;) {
         if (!done) {
@@ -727,11 +753,22 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int i = N - 1;
   if (i & 1) { step(i, std::integral_constant<int, 1>()); i--; }
-  for (; i >= 1; i -= 2) {
+  for (; i >= 1 && !(FAST && failed); i -= 2) {
     step(i, std::integral_constant<int, 0>());
+    if (FAST && failed) break;
     step(i - 1, std::integral_constant<int, 1>());
   }
-  if (i == 0) step(0, std::integral_constant<int, 0>());
+  if (i == 0 && !(FAST && failed)) step(0, std::integral_constant<int, 0>());
+  if constexpr (FAST) {
+    if (failed) {
+      // every LDS-DMA request of this wave must have landed before its LDS can go to another workgroup
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) { P.k2_redo[blockIdx.x] = 1; P.k2_hint[blockIdx.x] = 1; }
+      return;
+    }
+  } else {
+    if (lane == 0) P.k2_hint[blockIdx.x] = failed ? 1 : 0;
+  }
   store_gains(P.GK);
 #ifdef TOLG_STAMPS
   STAMP(7)

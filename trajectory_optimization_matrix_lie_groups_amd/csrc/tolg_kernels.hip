@@ -136,7 +136,8 @@ struct Params {
   double* ls_alpha;    // [Bp]     last alpha tried this iteration
   int* ls_accept;      // [Bp]     accepted alpha index or -1
   int* ls_slot;        // [Bp]     slot holding the accepted candidate in this stage or -1
-  int* k2_redo;        // [Bp/4]   groups of four whose sweep k_backward4 handed to k_backward3 (tolg_backward4.h)
+  int* k2_redo;        // [Bp/4]   groups of four the fast backward sweep handed to the full one (tolg_backward3.h, FAST)
+  int* k2_hint;        // [Bp/4]   ... and whether a group's last sweep needed the general path (then the fast attempt is skipped)
   int* ec_redo;        // [Bp]     trajectories k_expected_change_ring hands to k_expected_change (tolg_expected_change.h)
   double* ED;          // [N+1][Bp][32] rollout = 'linear': deviation e_i (0..11) and control step du_i (16..16+m) of the alpha = 1
                        //          linear rollout, written by k_expected_change_ring<.., STORE>
@@ -3345,6 +3346,7 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* ls_accept = c.take<int>(B);
   int* ls_slot = c.take<int>(B);
   int* k2_redo = c.take<int>(B / 4 + 1);
+  int* k2_hint = c.take<int>(B / 4 + 1);
   int* ec_redo = c.take<int>(B);
   int* ls_list = c.take<int>(2 * B);
   int* ls_count = c.take<int>(64);
@@ -3354,7 +3356,7 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   double* ED = c.take<double>((N + 1) * 32 * B);
   if (P) {
     P->ED = ED; P->affine = 0; P->pad3 = 0;
-    P->k2_redo = k2_redo;
+    P->k2_redo = k2_redo; P->k2_hint = k2_hint;
     P->ec_redo = ec_redo;
     P->ls_list = ls_list; P->ls_count = ls_count; P->ls_pos = ls_pos; P->LSC = LSC; P->LSD = LSD;
     P->slot_x = slot_x; P->slot_u = slot_u; P->Jtrial = Jtrial; P->dtrial = dtrial; P->ecc = ecc;
@@ -3395,6 +3397,10 @@ __global__ __launch_bounds__(256) void k_poison_lds() {
   for (int k = threadIdx.x; k < 8192; k += 256) junk[k] = __builtin_nan("");
   __syncthreads();
   if (junk[(threadIdx.x * 33) & 8191] == 0.0) __builtin_trap();  // keeps the stores alive; never true
+}
+static bool getenv_flag(const char* name) {  // (read at every call: a handful of launches per iteration; used by A/B tests only)
+  const char* e = getenv(name);
+  return e && e[0] == '1';
 }
 static bool poison_lds_mode() {
   static const bool v = [] { const char* e = getenv("TOLG_POISON_LDS"); return e && e[0] == '1'; }();
@@ -3539,6 +3545,7 @@ struct Timed {
   // (`ext`: the backward sweep's third form, the fused launch) hands the event pair to the dispatch itself
   // (hipExtLaunchKernelGGL: start / stop timestamps of the kernel's own completion signal, no extra packet).
   tolg_handle_s* h; hipStream_t st; int kind; bool on, ext;
+  bool count = true;  // false: its time adds to its kind, but it is not one more launch of the sweep (the redo behind the fast sweep)
   Timed(tolg_handle_s* h_, hipStream_t s, int k, bool ext_ = false) : h(h_), st(s), kind(k), ext(ext_) {
     on = h->timing;
     if (on && h->ev_used == h->ev_kind.size()) {  // grow the event pool: a long solve must not silently stop being timed
@@ -3558,7 +3565,7 @@ struct Timed {
   ~Timed() {
     if (on) {
       if (!ext) (void)hipEventRecord(h->ev[2 * h->ev_used + 1], st);
-      h->ev_kind[h->ev_used] = kind; h->ev_used++;
+      h->ev_kind[h->ev_used] = kind | (count ? 0 : 8); h->ev_used++;
     }
   }
 };
@@ -3572,7 +3579,7 @@ extern "C" int tolg_kernel_time(tolg_handle_t h, int32_t reset, double* ms_backw
   for (size_t i = 0; i < h->ev_used; i++) {
     (void)hipEventSynchronize(h->ev[2 * i + 1]);
     float ms = 0;
-    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) acc[h->ev_kind[i]] += ms;
+    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) acc[h->ev_kind[i] & 7] += ms;
     if (h->ev_kind[i] == 0) nb++;
   }
   if (ms_backward) *ms_backward = acc[0];
@@ -3616,23 +3623,32 @@ static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, cons
 template <int M>
 static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int it, int ms) {
   const bool dj = h->hc.diagJ != 0;
-  Timed t(h, st, 0, dj && h->prob.kind != TOLG_DYN_PENDULUM3D);  // the third form is one launch: timed through its dispatch
   ms = (ms ? 1 : 0) | (h->rec_closed ? 2 : 0);
   const dim3 grid(P.Bp / 4), blk(64);
   // diagonal inertia blocks and a constant input matrix (every reference script except the pendulum): the third form
   // of the sweep (tolg_backward3.h).  Dense inertia and the pendulum keep k_backward.
   if (dj && h->prob.kind != TOLG_DYN_PENDULUM3D) {
-    const bool al = P.al_lb != nullptr;
-    if (h->hc.grav == 0.0) {
-      if (al) t.launch(k_backward3<M, false, true>, grid, blk, P, it, ms);
-      else t.launch(k_backward3<M, false, false>, grid, blk, P, it, ms);
-    } else {
-      if (al) t.launch(k_backward3<M, true, true>, grid, blk, P, it, ms);
-      else t.launch(k_backward3<M, true, false>, grid, blk, P, it, ms);
+    const bool al = P.al_lb != nullptr, grav = h->hc.grav != 0.0;
+    // From the second sweep of a solve on: the fast kernel (no general path compiled in: 254 registers instead of 395), then
+    // the full kernel for the groups it handed back (flag bit 2) -- usually none.  The first sweep starts from mu = 1
+    // (traopt_controller.py:2394): straight to the full kernel; so do the one-sweep entry points (it < 0).
+    const bool fast = it > 0 && !getenv_flag("TOLG_K2_FULL_ONLY");
+    for (int pass = fast ? 0 : 1; pass < 2; pass++) {
+      Timed t(h, st, 0, true);  // each pass is one launch: timed through its dispatch
+      t.count = (pass == 0) || !fast;
+      const int fl = ms | ((pass == 1 && fast) ? 4 : 0);
+      if (pass == 0) {
+        if (!grav) { if (al) t.launch(k_backward3<M, false, true, true>, grid, blk, P, it, fl); else t.launch(k_backward3<M, false, false, true>, grid, blk, P, it, fl); }
+        else { if (al) t.launch(k_backward3<M, true, true, true>, grid, blk, P, it, fl); else t.launch(k_backward3<M, true, false, true>, grid, blk, P, it, fl); }
+      } else {
+        if (!grav) { if (al) t.launch(k_backward3<M, false, true, false>, grid, blk, P, it, fl); else t.launch(k_backward3<M, false, false, false>, grid, blk, P, it, fl); }
+        else { if (al) t.launch(k_backward3<M, true, true, false>, grid, blk, P, it, fl); else t.launch(k_backward3<M, true, false, false>, grid, blk, P, it, fl); }
+      }
+      LAUNCH_CHECK();
     }
-    LAUNCH_CHECK();
     return 0;
   }
+  Timed t(h, st, 0);
   if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
     if (dj) hipLaunchKernelGGL((k_backward<6, true, true, true>), grid, blk, 0, st, P, it, ms);
     else hipLaunchKernelGGL((k_backward<6, true, true, false>), grid, blk, 0, st, P, it, ms);
