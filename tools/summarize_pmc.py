@@ -11,14 +11,22 @@ import time
 
 
 def per_kernel(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    # (round 4: both kernels of the backward sweep have launches that leave at once; a launch counts only if it moved a tenth of
+    # what the kernel's largest launch moved, so the averages are per real sweep)
+    per = collections.defaultdict(float)
+    for r in rows:
+        per[(r["Kernel_Name"].split("(")[0], r["Dispatch_Id"])] += float(r["Counter_Value"])
+    big = collections.defaultdict(float)
+    for (k, _d), v in per.items():
+        big[k] = max(big[k], v)
     acc = collections.defaultdict(float)
     n = collections.defaultdict(set)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
+    for (k, d), v in per.items():
+        if v < 0.1 * big[k]:
             continue
-        k = r["Kernel_Name"].split("(")[0]
-        acc[k] += float(r["Counter_Value"])
-        n[k].add(r["Dispatch_Id"])
+        acc[k] += v
+        n[k].add(d)
     return {k: (acc[k] / len(n[k]), len(n[k])) for k in acc}
 
 
