@@ -3840,6 +3840,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       // measured: 432 -> 387 it/s; 512 rollout waves of the general MS step beside the expected-change kernel cost more
       // than the nearly empty second stage saves)
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
+      // (round 4: 1 + 12 + 7 instead of 1 + 4 + 8 + 7 -- one latency chain fewer -- measured: 455 -> 418 it/s; the twelve-wide
+      // stage rolls out eight step sizes nobody needed for most of its trajectories)
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, opt->rollout_linear))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear))) return rc;
       if (!so3_family(h->prob.kind))
