@@ -20,7 +20,7 @@ import csv, collections, json
 rows=[r for r in csv.DictReader(open("gpurun_out/${tag}_pmc_$p/run_counter_collection.csv"))]
 # the backward sweep is two kernels since round 4 and both have launches that leave at once (the fast sweep hands a group back on
 # entry, the full kernel behind it finds nothing flagged): a launch counts only if its heaviest counter reaches a tenth of the
-# kernel's largest -- the averages are per REAL sweep; the dropped launches are counted in `launches_dropped`
+# kernel's largest -- the averages are per REAL sweep; the dropped launches are counted in launches_dropped
 big=collections.defaultdict(float); per=collections.defaultdict(float)
 for r in rows:
     k=r["Kernel_Name"].split("(")[0]; v=float(r["Counter_Value"])
