@@ -1887,16 +1887,26 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
       RSTAMP(4)
       Nx = Fn;
     } else {
-      // line-search step: build the factors for this alpha from the stored defect
+      // line-search step (traopt_controller.py:2713-2716): x^_{i+1} = x_{i+1} Exp(alpha d_q) f_q(x_i,u_i)^-1 f_q(x^_i,u^_i),
+      // xi^_{i+1} = xi_{i+1} - f_xi(x_i,u_i) + alpha d_xi + f_xi(x^_i,u^_i).  The reference evaluates the nominal dynamics again
+      // for the two factors; with the stored defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}] they are functions of the nominal
+      // trajectory alone: f_q = x_{i+1} Exp(d_q), so x_{i+1} Exp(alpha d_q) f_q^-1 = x_{i+1} Exp((alpha - 1) d_q) x_{i+1}^-1
+      // (exponentials of one twist commute) and xi_{i+1} - f_xi + alpha d_xi = (alpha - 1) d_xi -- equal to the reference's
+      // factors up to the rounding of Exp(Log(X)) = X, which is the noise its own factors carry (note at the record layout).
+      // Round 4: no second dynamics evaluation and no closed-form Exp on the chain, the inputs requested at the top of the
+      // step: the 4-alpha stage of the merit search 0.78 -> see DESIGN section 5.
+      // (requesting d and x_{i+1} at the top of the step, with the gains, was measured: 25 more values live across the Log,
+      // 416 -> 447 registers, the stage 0.24 -> 0.31 ms; they are requested here)
       __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
-      double d[12];
+      double dms[12];
 #pragma unroll
-      for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
-      State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f_k<M, CT, PK>(DK, C, So, R.u);
-      Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
-                            se3_inverse(Fo.X));
-      V3 cw = Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8]);
-      V3 cv = Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11]);
+      for (int a = 0; a < 12; a++) dms[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
+      const State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+      const double am1 = alpha - 1.0;
+      const Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp_fast(am1 * v3(dms[0], dms[1], dms[2]), am1 * v3(dms[3], dms[4], dms[5]))),
+                                  se3_inverse(Sx.X));
+      const V3 cw = am1 * v3(dms[6], dms[7], dms[8]);
+      const V3 cv = am1 * v3(dms[9], dms[10], dms[11]);
       RSTAMP(4)
       Nx.X = se3_project(se3_compose(Mx, Fn.X));
       Nx.w = cw + Fn.w;
@@ -2591,12 +2601,14 @@ __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nsl
         double d[12];
 #pragma unroll
         for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
-        State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB), Fo = dyn_f<M>(C, So, u);
-        Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp(alpha * v3(d[0], d[1], d[2]), alpha * v3(d[3], d[4], d[5]))),
-                              se3_inverse(Fo.X));
+        // the factors from the stored defect alone (note in roll_step): x_{i+1} Exp((alpha - 1) d_q) x_{i+1}^-1, (alpha - 1) d_xi
+        const State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+        const double am1 = alpha - 1.0;
+        const Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp_fast(am1 * v3(d[0], d[1], d[2]), am1 * v3(d[3], d[4], d[5]))),
+                                    se3_inverse(Sx.X));
         Nx.X = se3_project(se3_compose(Mx, Fn.X));
-        Nx.w = (Sx.w - Fo.w + alpha * v3(d[6], d[7], d[8])) + Fn.w;
-        Nx.v = (Sx.v - Fo.v + alpha * v3(d[9], d[10], d[11])) + Fn.v;
+        Nx.w = am1 * v3(d[6], d[7], d[8]) + Fn.w;
+        Nx.v = am1 * v3(d[9], d[10], d[11]) + Fn.v;
       } else {
         Nx = Fn;  // SS: x^_{i+1} = f(x^_i, u^_i) (traopt_controller.py:2073-2080)
       }
