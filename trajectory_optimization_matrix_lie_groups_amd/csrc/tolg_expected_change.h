@@ -212,9 +212,20 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     const char* sl = lds + SLOT * EC_SLOT;
     auto ld = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(sl + off); };
     // knot i was requested EC_DEPTH - 1 steps ago; behind it at most the requests of knots i + 1 .. i + EC_DEPTH - 2
-    // (STORE: behind knot i's request also sit the two stores of each of the last EC_DEPTH - 1 steps)
+    // (STORE: behind knot i's request also sit the two stores of each of the last EC_DEPTH - 1 steps -- once that many steps
+    // have run.  The first EC_DEPTH - 1 steps have fewer stores behind the request and take the count without them, which
+    // waits for a little more than it must; with the full count they did not wait for the DMA at all when it was late: a race
+    // that one run in some dozens lost, found as a flaky linear-rollout case.)
     constexpr int NST = STORE ? 2 * (EC_DEPTH - 1) : 0;
-    if (i + EC_DEPTH - 2 <= N - 1) {
+    if (STORE && i < EC_DEPTH - 1) {
+      if (i + EC_DEPTH - 2 <= N - 1) {
+        if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7) : "memory");
+        else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if (i + EC_DEPTH - 2 <= N - 1) {
       if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7 + NST) : "memory");
       else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6 + NST) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5 + NST) : "memory");
