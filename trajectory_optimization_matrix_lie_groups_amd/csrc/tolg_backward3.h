@@ -763,11 +763,14 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     if (failed) {
       // every LDS-DMA request of this wave must have landed before its LDS can go to another workgroup
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) { P.k2_redo[blockIdx.x] = 1; P.k2_hint[blockIdx.x] = 1; }
+      if (lane == 0) { P.k2_redo[blockIdx.x] = 1; P.k2_hint[blockIdx.x] = 8; }
       return;
     }
   } else {
-    if (lane == 0) P.k2_hint[blockIdx.x] = failed ? 1 : 0;
+    // (the hint counts down: a sweep that needed the general path keeps the group on the full kernel for the next eight sweeps,
+    // each clean one takes one off -- a group that alternates between clean and regularised sweeps, which single shooting with
+    // dense inertia blocks does, would otherwise pay for a fast attempt that dies half way every other sweep)
+    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
   }
   store_gains(P.GK);
 #ifdef TOLG_STAMPS

@@ -1302,19 +1302,33 @@ TOLG_DEV void ldl_solve(const double (&a)[M], const double (&rinv)[M], double (&
 // without it and save its 18 per-lane coefficients (36 VGPRs in a kernel that already spills to AGPRs).
 // DIAGJ: I_b and J_v are diagonal (every reference script): F_u's two 3x3 blocks are diagonal (the drone's
 // J_v^-1 e_z column has one entry), so each input touches one row of (V + mu I) F_x instead of three.
-template <int M, bool VARB = false, bool GRAV = true, bool DIAGJ = false>
+// FAST (round 4): as for k_backward3 (tolg_backward3.h) -- only the first, unregularised attempt compiled in; a group that meets
+// anything else is flagged in P.k2_redo and redone by the full kernel launched behind (flag bit 2), P.k2_hint keeps groups whose
+// last sweep needed the retry loop away from the fast attempt.
+template <int M, bool VARB = false, bool GRAV = true, bool DIAGJ = false, bool FAST = false>
 __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
   // flags: bit 0 multiple shooting; bit 1 the records come from the fused rollout, whose trajectories are closed
-  // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here
+  // (x_{i+1} = f(x_i, u_i)): the defect field is not written there and reads as zero here; bit 2: only the groups the fast
+  // kernel handed back
+  if ((flags & 4) && !P.k2_redo[blockIdx.x]) return;
   const int ms = flags & 1;
   const bool closed = (flags & 2) != 0;
   const DConsts& C = *(const DConsts*)P.c;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
   const bool act = P.active[b] != 0;
+  if constexpr (FAST) {
+    const bool back = __any(act && P.mu[b] != 0.0) || P.k2_hint[blockIdx.x] != 0;
+    if (lane == 0) P.k2_redo[blockIdx.x] = back ? 1 : 0;
+    if (back) return;
+  }
+  bool failed = false;  // FAST: a knot the first attempt did not settle; full kernel: the retry loop ran somewhere (-> k2_hint)
   if (!__any(act)) return;
   const int N = P.N;
-  __shared__ double TR[4][12 * 13];
+  // (FAST: 252 registers would let two workgroups share a SIMD, and the dispatcher then packs some SIMDs with two waves and
+  // leaves others idle -- the dense-inertia SS bench ran this kernel at 0.62 ms against 0.41 with an even spread; the transpose
+  // scratch is over-allocated to 35 KB so that a CU takes four workgroups, one per SIMD)
+  __shared__ double TR[FAST ? 28 : 4][12 * 13];
   __shared__ double TRZ[12];  // zeros: what the vector lanes "transpose-read" (see the symmetrisation below)
 
   // lane-dependent constants
@@ -1609,14 +1623,23 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
     // for the loop-carried factors.  The retry loop itself is entered only when some active trajectory
     // of this wavefront failed the PD test.
     bool done = true;
-    {
+    if constexpr (FAST) {
+      // mu = 0 on entry and for as long as every pivot is positive (schedule(true) keeps it there); a non-positive pivot
+      // anywhere in the wave ends the sweep behind this step (no branch in mid-step) and the full kernel redoes the group
       const bool pd = attempt();
-      if (act) done = schedule(pd);
-    }
-    if (!__all(done)) {
-      for (;;) {
-        if (!done) done = schedule(attempt());
-        if (__all(done)) break;
+      failed = failed || __any(act && !pd);
+      if (act) { delta = fmin(1.0, delta) * 0.5; mu = 0.0; }
+    } else {
+      {
+        const bool pd = attempt();
+        if (act) done = schedule(pd);
+      }
+      if (!__all(done)) {
+        failed = true;
+        for (;;) {
+          if (!done) done = schedule(attempt());
+          if (__all(done)) break;
+        }
       }
     }
     STAMP(4)
@@ -1630,7 +1653,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
     // gains: [K | k] = -Q_uu^-1 [Q_ux | Q_u]; the adjoint lane gets none (kneg: -1, or 0 in that lane)
 #pragma unroll
     for (int u = 0; u < M; u++) Kh[u] = Quh[u];
-    if (__any(use_lu)) {
+    if (!FAST && __any(use_lu)) {
       // max-regularisation exit with a non-PD Q_uu: np.linalg.solve semantics on the matrix itself (rare path:
       // rebuild it -- the factorisation ran in place -- and replicate it to every lane)
       double Kl[M], Ac[M][M], Qc[M];
@@ -1676,7 +1699,18 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
 
   BwdIn in;
   load_knot(N - 1, in);
-  for (int i = N - 1; i >= 0; i--) step(i, in);
+  for (int i = N - 1; i >= 0 && !(FAST && failed); i--) step(i, in);
+  if constexpr (FAST) {
+    if (failed) {
+      if (lane == 0) { P.k2_redo[blockIdx.x] = 1; P.k2_hint[blockIdx.x] = 8; }
+      return;
+    }
+  } else {
+    // (the hint counts down: a sweep that needed the general path keeps the group on the full kernel for the next eight sweeps,
+    // each clean one takes one off -- a group that alternates between clean and regularised sweeps, which single shooting with
+    // dense inertia blocks does, would otherwise pay for a fast attempt that dies half way every other sweep)
+    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
+  }
   store_gains(0);
 #ifdef TOLG_STAMPS
   STAMP(7)
@@ -3660,18 +3694,24 @@ static int run_backward(tolg_handle_s* h, const Params& P, hipStream_t st, int i
     }
     return 0;
   }
-  Timed t(h, st, 0);
-  if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
-    if (dj) hipLaunchKernelGGL((k_backward<6, true, true, true>), grid, blk, 0, st, P, it, ms);
-    else hipLaunchKernelGGL((k_backward<6, true, true, false>), grid, blk, 0, st, P, it, ms);
-  } else if (M == 6 && h->hc.grav == 0.0) {
-    if (dj) hipLaunchKernelGGL((k_backward<6, false, false, true>), grid, blk, 0, st, P, it, ms);
-    else hipLaunchKernelGGL((k_backward<6, false, false, false>), grid, blk, 0, st, P, it, ms);
-  } else {
-    if (dj) hipLaunchKernelGGL((k_backward<M, false, true, true>), grid, blk, 0, st, P, it, ms);
-    else hipLaunchKernelGGL((k_backward<M, false, true, false>), grid, blk, 0, st, P, it, ms);
+  // dense inertia blocks, the pendulum: the general sweep, in the same two passes
+  const bool fast = it > 0 && !getenv_flag("TOLG_K2_FULL_ONLY");
+  for (int pass = fast ? 0 : 1; pass < 2; pass++) {
+    Timed t(h, st, 0, true);
+    t.count = (pass == 0) || !fast;
+    const int fl = ms | ((pass == 1 && fast) ? 4 : 0);
+    if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
+      if (pass == 0) { if (dj) t.launch(k_backward<6, true, true, true, true>, grid, blk, P, it, fl); else t.launch(k_backward<6, true, true, false, true>, grid, blk, P, it, fl); }
+      else { if (dj) t.launch(k_backward<6, true, true, true, false>, grid, blk, P, it, fl); else t.launch(k_backward<6, true, true, false, false>, grid, blk, P, it, fl); }
+    } else if (M == 6 && h->hc.grav == 0.0) {
+      if (pass == 0) t.launch(k_backward<6, false, false, false, true>, grid, blk, P, it, fl);
+      else t.launch(k_backward<6, false, false, false, false>, grid, blk, P, it, fl);
+    } else {
+      if (pass == 0) t.launch(k_backward<M, false, true, false, true>, grid, blk, P, it, fl);
+      else t.launch(k_backward<M, false, true, false, false>, grid, blk, P, it, fl);
+    }
+    LAUNCH_CHECK();
   }
-  LAUNCH_CHECK();
   return 0;
 }
 template <int M>
