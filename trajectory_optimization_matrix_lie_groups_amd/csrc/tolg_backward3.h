@@ -559,6 +559,7 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // regularisation schedule (traopt_controller.py:2975-2995); returns true when this knot is settled
     auto schedule = [&](bool pd) -> bool {
       if (!pd) {
+        if constexpr (!FAST) failed = true;  // (full kernel: a non-positive pivot in this sweep -> P.k2_hint; per lane, any-reduced at the end)
         delta = fmax(1.0, delta) * 2.0;
         mu = fmax(1e-6, mu * delta);
         if (P.max_reg > 0 && mu >= P.max_reg) { warned = 1; use_lu = true; return true; }
@@ -682,7 +683,6 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     if constexpr (FAST) {
       if (!settled) { failed = true; return; }  // a non-positive pivot: the full kernel redoes this group (wave-uniform)
     } else if (!settled) {
-      failed = true;  // (full kernel: "this sweep needed the general path" -> P.k2_hint)
       double Y2[M], U2[M], nr2[M], d2[M];
       for (;;) {
         if (!done) {
@@ -767,10 +767,12 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
       return;
     }
   } else {
-    // (the hint counts down: a sweep that needed the general path keeps the group on the full kernel for the next eight sweeps,
-    // each clean one takes one off -- a group that alternates between clean and regularised sweeps, which single shooting with
-    // dense inertia blocks does, would otherwise pay for a fast attempt that dies half way every other sweep)
-    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
+    // (the hint counts down: a sweep that met a non-positive pivot keeps the group on the full kernel for the next eight sweeps,
+    // each clean one takes one off -- a group that alternates between clean and regularised sweeps would otherwise pay for a
+    // fast attempt that dies half way every other sweep.  Regularisation that is merely left over on entry and decays -- the
+    // first sweep of every solve starts from mu = 1 -- does not count: the fast kernel checks mu itself.)
+    const bool anyf = __any(failed);
+    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = anyf ? 8 : (hn > 0 ? hn - 1 : 0); }
   }
   store_gains(P.GK);
 #ifdef TOLG_STAMPS

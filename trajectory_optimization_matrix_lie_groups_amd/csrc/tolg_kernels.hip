@@ -1706,9 +1706,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
       return;
     }
   } else {
-    // (the hint counts down: a sweep that needed the general path keeps the group on the full kernel for the next eight sweeps,
-    // each clean one takes one off -- a group that alternates between clean and regularised sweeps, which single shooting with
-    // dense inertia blocks does, would otherwise pay for a fast attempt that dies half way every other sweep)
+    // (the hint counts down from eight after a sweep with a non-positive pivot: note in tolg_backward3.h)
     if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
   }
   store_gains(0);
