@@ -72,7 +72,9 @@ typedef struct {
   int32_t mode;            /* TOLG_MODE_MS | TOLG_MODE_SS */
   int32_t max_iter;        /* n_iterations */
   int32_t line_search;     /* MS: merit-function search (:2549-2590); SS always backtracks */
-  int32_t rollout_linear;  /* rollout == 'linear' */
+  int32_t rollout_linear;  /* rollout == 'linear' (the reference constructors' default, :1837-1838, :2359-2363): on the device the
+                              linear rollout is an affine recursion in the deviation, linear in the step size -- one sweep serves
+                              every candidate of a line search (DESIGN.md section 4 "Linear rollouts") */
   double tol_grad;         /* tol_grad_norm */
   double tol_defect;       /* tol_d_norm (MS) */
   double max_reg;          /* max_reg (1e10) */

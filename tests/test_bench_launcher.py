@@ -9,6 +9,8 @@ import subprocess
 import sys
 import time
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
@@ -115,3 +117,23 @@ def test_lib_override_is_refused_without_the_flag(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode != 0 and "--allow-lib-override" in (out.stderr + out.stdout)
+
+
+def test_profile_lookups_pick_the_fast_sweep_and_fresh_series_shape():
+    """bench.py's helpers that read the committed profiles: since round 4 the backward sweep is two kernels and the headline's
+    dominant one is the fast sweep (`k_backward3<.., true>`); the executed-fp64 figure sums it and the fused launch; the fresh-solve
+    series reports the median of the regions without per-kernel events."""
+    ks = {"void tolg::k_backward3<6, false, false, false>": {"SQ_WAVES": 1024.0, "SQ_INSTS_VALU_FMA_F64": 1.0},
+          "void tolg::k_backward3<6, false, false, true>": {"SQ_WAVES": 1024.0, "SQ_INSTS_VALU_FMA_F64": 2.0},
+          "void tolg::k_rollout_lin<6>": {"SQ_WAVES": 1024.0, "SQ_INSTS_VALU_FMA_F64": 3.0}}
+    name, v = bench._pick_kernel(ks, "k_backward3")
+    assert name.endswith("true>") and v["SQ_INSTS_VALU_FMA_F64"] == 2.0
+    assert bench._pick_kernel(ks, "k_rollout_lin")[0].endswith("k_rollout_lin<6>")
+    assert bench._pick_kernel({"void tolg::k_backward3<6, false, false>": {}}, "k_backward3")[0].endswith("false>")   # round-3 profiles
+    assert bench._pick_kernel(ks, "k_nothing") == (None, None)
+    fr = bench.fresh_series([(0.012, True, (0.30, 0.25, 0.0)), (0.011, False, None), (0.013, True, (0.31, 0.24, 0.0)), (0.0115, False, None)],
+                            20, 5, 1.0, 1, 0.54)
+    assert fr["regions"] == 4 and fr["median_ms_per_step"] == pytest.approx(0.5625) and fr["value"] == pytest.approx(20 / 0.01125)
+    assert fr["kernel_ms_per_step"]["backward"] == pytest.approx(0.305) and fr["ratio_to_headline_ms_per_step"] == pytest.approx(0.5625 / 0.54)
+    ex = bench.executed_fp64_fraction(0.54)   # from the committed profiles/*_sq_mix.json
+    assert ex is None or (0.1 < ex["frac"] < 1.0 and len(ex["kernels"]) == 2)
