@@ -416,6 +416,13 @@ TOLG_DEV State dyn_f_k(const DynK& K, const CT& C, const State& S, const double 
   return F;
 }
 
+// dyn_f_k for kernels that serve every model: the pendulum decided at run time (kernel-uniform)
+template <int M, class CT>
+TOLG_DEV State dyn_f_any(const DynK& K, const CT& C, const State& S, const double (&u)[M]) {
+  if (C.kind == TOLG_DYN_PENDULUM3D) return dyn_f_k<M, CT, 1>(K, C, S, u);
+  return dyn_f_k<M, CT, 0>(K, C, S, u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // pack / unpack between the reference's 4x4 AoS layout (C ABI) and the device SoA layout
 // ------------------------------------------------------------------------------------------------
@@ -1861,10 +1868,13 @@ struct RStamps { unsigned long long acc[8], t; };
 // what the line-search evaluation and the expected-cost-change kernels need from inside a step
 template <int M>
 struct RollProbe { double e[12], du[M]; State Fn; };
+// what a caller of the merit search's step (alpha < 1) may already hold of the NOMINAL trajectory: the defect d_i (have_d) and
+// x_{i+1} (have_x) -- by value, so that they stay in registers
+struct RollPre { bool have_d = false, have_x = false; double d[12]; State Sx; };
 template <int M, bool LINEAR, bool ALPHA1, int PK, bool STORE, class CT, class LoadFn>
 TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, int b, int q, bool writer, unsigned vb,
                          unsigned sB, double alpha, const State& So, const State& Sn, double (&un_out)[M],
-                         LoadFn load_in, RollProbe<M>* probe RST_PARAM) {
+                         LoadFn load_in, RollProbe<M>* probe RST_PARAM, const RollPre& pre = RollPre()) {
   const size_t stStride = (size_t)13 * P.Bp, recStride = (size_t)P.recF * P.Bp, uStride = (size_t)M * P.Bp;
   RSTAMP(0)
   RollIn<M> R;
@@ -1929,11 +1939,13 @@ TOLG_DEV State roll_step(const Params& P, const CT& C, const DynK& DK, int i, in
       // step: the 4-alpha stage of the merit search 0.78 -> see DESIGN section 5.
       // (requesting d and x_{i+1} at the top of the step, with the gains, was measured: 25 more values live across the Log,
       // 416 -> 447 registers, the stage 0.24 -> 0.31 ms; they are requested here)
+      // SxPre / dPre: the caller already holds x_{i+1} (its next nominal state, fetched a knot ahead) and the defect of this
+      // knot (fetched with it): nothing is requested on the chain then
       __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
       double dms[12];
 #pragma unroll
-      for (int a = 0; a < 12; a++) dms[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
-      const State Sx = load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
+      for (int a = 0; a < 12; a++) dms[a] = pre.have_d ? pre.d[a] : bld(rR, REC_VR(b), FOFF(REC_D + a));
+      const State Sx = pre.have_x ? pre.Sx : load_state_b(mkbuf(P.cur + stStride * (i + 1), 13 * sB), vb, sB);
       const double am1 = alpha - 1.0;
       const Pose Mx = se3_compose(se3_compose(Sx.X, se3_exp_fast(am1 * v3(dms[0], dms[1], dms[2]), am1 * v3(dms[3], dms[4], dms[5]))),
                                   se3_inverse(Sx.X));
@@ -2592,6 +2604,9 @@ TOLG_DEV double knot_cost(const Params& P, const Consts& C, int i, int b, const 
 template <int M, bool MS, bool LINEAR>
 __global__ __launch_bounds__(64) void k_rollout_eval_t(Params P, int a0, int nslots, int list) {
   const Consts& C = *P.c;
+  // (round 4: the series forms of tolg_lie.h in this kernel and in k_ls_eval were measured -- SS 414 -> 404, merit 500 -> 482: a
+  // wave of 64 unrelated (trajectory, alpha) pairs nearly always holds a lane that needs the long tier or the fallback, and then
+  // runs all three; the closed forms stay)
   const int b = blockIdx.x * 64 + threadIdx.x, slot = blockIdx.y;
   if (b >= P.Bp || slot >= nslots) return;
   if (ls_quad_form(P, list, nslots)) return;  // the quad form's turn
@@ -2747,18 +2762,43 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
   };
   // K3's loop: two steps per trip, the nominal state fetched two knots ahead into ping-pong registers.  Single shooting
   // steps x^+ = f(x^, u^) for every alpha (:2073-2080): roll_step's ALPHA1 form
+  // The merit search's step (alpha < 1: roll_step's factor form) also needs x_{i+1} and the stored defect d_i of the NOMINAL
+  // trajectory: x_{i+1} is the state this loop fetches ahead anyway, d_i rides in a second ping-pong pair fetched with it
+  // (round 4: requested inside the step, behind the gain product, their latency sat on the chain of every knot)
+  constexpr bool FACT = MS && !LINEAR;
+  const size_t recStride = (size_t)P.recF * P.Bp;
+  double dA[FACT ? 12 : 1], dB[FACT ? 12 : 1];
+  auto load_d = [&](int i, double (&d)[FACT ? 12 : 1]) {
+    if constexpr (FACT) {
+      __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
+#pragma unroll
+      for (int a = 0; a < 12; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
+    }
+  };
+  auto mkpre = [&](const double (&d)[FACT ? 12 : 1], const State& Sx, bool have_x) {
+    RollPre pr;
+    if constexpr (FACT) {
+      pr.have_d = true; pr.have_x = have_x; pr.Sx = Sx;
+#pragma unroll
+      for (int a = 0; a < 12; a++) pr.d[a] = d[a];
+    }
+    return pr;
+  };
   State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+  load_d(0, dA);
   for (int i = 0; i < N; i += 2) {
-    if (i + 1 < N) Sb = roll_load_state(P, i + 1, vb, sB);
+    if (i + 1 < N) { Sb = roll_load_state(P, i + 1, vb, sB); load_d(i + 1, dB); }
     __builtin_amdgcn_sched_barrier(0);
     Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i, b, q, writer, vb, sB, alpha, Sa, Sn, un,
-                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG);
+                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i, b, q, vb, sB, R); }, nullptr RST_ARG,
+                                               mkpre(dA, Sb, i + 1 < N));
     store(i);
     if (i + 1 >= N) break;
-    if (i + 2 < N) Sa = roll_load_state(P, i + 2, vb, sB);
+    if (i + 2 < N) { Sa = roll_load_state(P, i + 2, vb, sB); load_d(i + 2, dA); }
     __builtin_amdgcn_sched_barrier(0);
     Sn = roll_step<M, LINEAR, !MS, PK, false>(P, C, DK, i + 1, b, q, writer, vb, sB, alpha, Sb, Sn, un,
-                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i + 1, b, q, vb, sB, R); }, nullptr RST_ARG);
+                                               [&](RollIn<M>& R) { roll_load<M, !MS>(P, i + 1, b, q, vb, sB, R); }, nullptr RST_ARG,
+                                               mkpre(dB, Sa, i + 2 < N));
     store(i + 1);
   }
 }
@@ -2843,7 +2883,9 @@ TOLG_DEV void affine_candidate(const Params& P, int i, int b, double alpha, Stat
   } else {
     // x_i (+) alpha e_i: the right-plus of :2730-2733 (q_next_mnf + tangent), re-normalised like every group operation here
     const f64x2 e0 = ed[0], e1 = ed[1], e2 = ed[2], e3 = ed[3], e4 = ed[4], e5 = ed[5];
-    const Pose D = se3_exp_fast(alpha * v3(e0.x, e0.y, e1.x), alpha * v3(e1.y, e2.x, e2.y));
+    // (closed forms here and in k_ls_eval_affine: the series forms were measured slower in these one-thread-per-(trajectory,
+    // knot, alpha) kernels -- linear merit 354 against 375 it/s -- for the reason noted at k_rollout_eval_t)
+    const Pose D = se3_exp(alpha * v3(e0.x, e0.y, e1.x), alpha * v3(e1.y, e2.x, e2.y));
     S.X = se3_project(se3_compose(So.X, D));
     S.w = So.w + alpha * v3(e3.x, e3.y, e4.x);
     S.v = So.v + alpha * v3(e4.y, e5.x, e5.y);
@@ -2877,16 +2919,15 @@ __global__ __launch_bounds__(256) void k_ls_eval_affine(Params P, int a0, int ns
   State S;
   double u[M];
   affine_candidate<M>(P, i, b, alpha, S, u);
-  P.LSC[((size_t)slot * (N + 1) + i) * P.Bp + e] = knot_cost<M, true>(P, C, i, b, S, u, i == N);
+  P.LSC[((size_t)slot * (N + 1) + i) * P.Bp + e] = knot_cost<M>(P, C, i, b, S, u, i == N);
   if constexpr (MS) {
     if (i < N) {
       State Nx;
       double un[M];
       affine_candidate<M>(P, i + 1, b, alpha, Nx, un);
-      const DynK DK = dynk_load(C);
-      const State Fn = dyn_f_k<M, Consts, 0>(DK, C, S, u);
+      const State Fn = dyn_f<M>(C, S, u);
       V3 dw, dv;
-      se3_log_fast(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
+      se3_log(se3_compose(se3_inverse(Nx.X), Fn.X), dw, dv);
       const V3 xw = Fn.w - Nx.w, xv = Fn.v - Nx.v;
       P.LSD[((size_t)slot * N + i) * P.Bp + e] = dot(dw, dw) + dot(dv, dv) + dot(xw, xw) + dot(xv, xv);
     }
