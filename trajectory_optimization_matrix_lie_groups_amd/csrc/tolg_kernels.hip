@@ -856,17 +856,30 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
   }
 }
 
+TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots);  // (line-search stages, below)
 template <int M>
 __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
                                                     const double* __restrict__ src_u, double* __restrict__ dst,
-                                                    double* __restrict__ dst_u, int ms, int i0, int ni) {
-  // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read
+                                                    double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots) {
+  // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read.
+  // ls_nslots > 0 (round 4): the candidates the LAST stage of a line search accepted are read where that stage left them -- slot
+  // ls_slot[b], at the trajectory's position on the stage's list or at b (k_ls_copy's rule) -- instead of behind a copy into the
+  // candidate arrays; everything accepted earlier is in the candidate arrays (src) as before
   const DConsts& C = *(const DConsts*)P.c;
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (size_t)ni * P.Bp) return;
   const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
   if (!P.active[b]) return;
-  State S = load_state(P, src, i, b);
+  int e = b;
+  if (ls_nslots > 0) {
+    const int sl = P.ls_slot[b];
+    if (sl >= 0) {
+      e = (ls_list >= 0 && ls_quad_form(P, ls_list, ls_nslots)) ? P.ls_pos[(size_t)ls_list * P.Bp + b] : b;
+      src = P.slot_x + (size_t)sl * 13 * P.Bp * (P.N + 1);
+      src_u = P.slot_u + (size_t)sl * M * P.Bp * P.N;
+    }
+  }
+  State S = load_state(P, src, i, e);
   if (dst) store_state(P, dst, i, b, S);
   double u[M];
 #pragma unroll
@@ -874,11 +887,11 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   if (i < P.N) {
 #pragma unroll
     for (int a = 0; a < M; a++) {
-      u[a] = src_u[UIDX(a, i, b)];
+      u[a] = src_u[UIDX(a, i, e)];
       if (dst_u) dst_u[UIDX(a, i, b)] = u[a];
     }
   }
-  lin_knot<M>(P, C, i, b, ms, S, u, [&]() { return load_state(P, src, i + 1, b); });
+  lin_knot<M>(P, C, i, b, ms, S, u, [&]() { return load_state(P, src, i + 1, e); });
 }
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
@@ -3695,13 +3708,13 @@ static Params params_for(tolg_handle_s* h, int B) {
 
 template <int M>
 static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, const double* src, const double* src_u,
-                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1) {
+                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1, int ls_list = -1, int ls_nslots = 0) {
   if (ni < 0) ni = P.N + 1;
   size_t n = (size_t)ni * P.Bp;
   h->rec_closed = 0;  // K1 writes the defect field
   Timed t(h, st, 2);
   hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms,
-                     i0, ni);
+                     i0, ni, ls_list, ls_nslots);
   LAUNCH_CHECK();
   return 0;
 }
@@ -3793,7 +3806,7 @@ static int run_affine_dev(tolg_handle_s* h, const Params& P, hipStream_t st, boo
 // A one-alpha stage writes its candidate in place (no slot, no copy).
 template <int M, bool MS>
 static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int stage, int a0, int n, int linear,
-                        hipEvent_t before_select = nullptr) {
+                        hipEvent_t before_select = nullptr, bool last = false) {
   const int direct = n == 1;
   if (n > NSLOT) return TOLG_E_ARG;
   const bool pend = M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D;
@@ -3841,7 +3854,10 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
   hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, a0, n, list_out);
   LAUNCH_CHECK();
-  if (!direct) {
+  // the last stage of a search leaves its accepted candidates in their slots: k_linearize reads them there (no copy).  Not in a
+  // solve on the affine path, whose candidates exist only where k_affine_commit writes them
+  const bool keep = last && !direct && !P.affine;
+  if (!direct && !keep) {
     size_t nn = (size_t)(P.N + 1) * P.Bp;
     hipLaunchKernelGGL(k_ls_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, list_in, n);
     LAUNCH_CHECK();
@@ -3851,8 +3867,11 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
     hipLaunchKernelGGL(k_affine_commit<M>, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P, a0, 0);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, list_out ^ 1);
-  LAUNCH_CHECK();
+  if (!keep) {  // (kept: k_linearize still needs ls_slot AND the length of this stage's list, which decides where a candidate lies;
+                // k_ls_begin resets both at the top of the next iteration)
+    hipLaunchKernelGGL(k_ls_clear_slot, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, list_out ^ 1);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -3861,6 +3880,7 @@ template <int M>
 static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
+    int ls_list_last = -1, ls_n_last = 0;  // set by the merit search below: where its last stage left what it accepted
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
     if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
         opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block) {
@@ -3933,15 +3953,19 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
       // (round 4: 1 + 12 + 7 instead of 1 + 4 + 8 + 7 -- one latency chain fewer -- measured: 455 -> 418 it/s; the twelve-wide
       // stage rolls out eight step sizes nobody needed for most of its trajectories)
+      // (the last stage leaves what it accepted in its slots: the re-linearisation reads it there)
+      const bool so3f = so3_family(h->prob.kind);
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, opt->rollout_linear))) return rc;
-      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear))) return rc;
-      if (!so3_family(h->prob.kind))
-        if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, opt->rollout_linear))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear, nullptr, so3f))) return rc;
+      if (!so3f)
+        if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, opt->rollout_linear, nullptr, true))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
+      ls_list_last = so3f ? 1 : 0;   // the list the last stage ran on: (stage - 1) & 1
+      ls_n_last = so3f ? 8 : 7;
     }
     // the accepted candidate becomes the nominal trajectory while it is re-linearised
-    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1))) return rc;
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last))) return rc;
     hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
   }
@@ -3962,10 +3986,12 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     // (1 + 4 + 8 like the merit search was measured: 405 -> 339 it/s on iterations 3..23 of the benchmark solve, whose
     // searches end at the 6th to 10th step size -- tools/ls_alpha_histogram.py; it would pay from iteration ~45 on, where
     // the median accepted step size is the second one)
-    if ((rc = run_ls_stage<M, false>(h, P, st, 1, 1, NALPHA_SS - 1, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 1, 1, NALPHA_SS - 1, opt->rollout_linear, nullptr, true))) return rc;
     hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
-    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0))) return rc;
+    // (what the twelve-alpha stage accepted is read from its slots -- no k_ls_copy: 0.15-0.2 ms of a 2.4 ms iteration; on the
+    // affine path the candidates are in the candidate arrays, where k_affine_commit wrote them)
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0, 0, -1, 0, P.affine ? 0 : NALPHA_SS - 1))) return rc;
     hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
   }
