@@ -91,6 +91,9 @@ typedef Consts DConsts;  // the host pass only parses the kernels
 #ifndef TOLG_NT_GKST
 #define TOLG_NT_GKST 1
 #endif
+#ifndef TOLG_NT_RECST_K1   // the record stores of k_linearize (line-search modes, split schedule), tuned on their own
+#define TOLG_NT_RECST_K1 0
+#endif
 #ifndef TOLG_NT_CURST
 #define TOLG_NT_CURST 1
 #endif
@@ -144,9 +147,12 @@ struct Params {
   int affine, pad3;    // this solve takes its linear-rollout candidates from ED (every trajectory with ec_redo == 0)
   // line search, round 3 form: the stages roll out only (quad rollouts over a compacted list of the undecided
   // trajectories), costs and defects of the candidates are evaluated in parallel over the knots
-  int* ls_list;        // [2][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
-  int* ls_count;       // [2]      ... the stage's kernels still read the current one
-  int* ls_pos;         // [2][Bp]  position of a trajectory on its list: the quad form keeps a stage's candidates densely, by position
+  int* ls_list;        // [3][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
+  int* ls_count;       // [3]      ... the stage's kernels still read the current one; list 2: the trajectories the speculative
+                       //          first stage (k_rollout_lin<M, true>) did NOT settle, kept until the re-linearisation
+  int* ls_pos;         // [3][Bp]  position of a trajectory on its list: the quad form keeps a stage's candidates densely, by position
+  double* REC2;        // the other record buffer of a line-search solve: the speculative first stage and the re-linearisation
+                       // write the NEXT iteration's records there while the search still reads this iteration's (host swaps)
   double* LSC;         // [NSLOT][N+1][Bp] stage costs of the candidates
   double* LSD;         // [NSLOT][N][Bp]   squared defects of the candidates (MS)
   // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
@@ -589,10 +595,9 @@ TOLG_DEV void a22_get(const Params& P, const Consts& C, int i, int b, double (&a
 }
 
 // N consecutive record fields from F0, as 16-byte stores wherever a field pair is complete
-template <int F0, int N>
+template <int F0, int N, int NT = TOLG_NT_RECST>
 TOLG_DEV void rec_run(const Params& P, int i, int b, const double (&v)[N]) {
   constexpr int H = F0 & 1;  // an odd first field goes alone
-  constexpr int NT = TOLG_NT_RECST;
   if constexpr (H) gst<NT>(&P.REC[RIDX(i, F0, b)], v[0]);
 #pragma unroll
   for (int k = H; k + 1 < N; k += 2) {
@@ -622,6 +627,8 @@ template <int M, bool CLOSED = false, int TERM = -1, class CT, class NextFn>
 TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const State& S, const double (&u)[M],
                        NextFn next_state, double* lcost = nullptr) {
   const bool term = TERM < 0 ? (i == P.N) : (TERM == 1);
+  // store policy of the record: the fused launch's helpers (CLOSED) and K1 on its own were tuned separately (TOLG_NT_* note)
+  constexpr int RP = CLOSED ? TOLG_NT_RECST : TOLG_NT_RECST_K1;
   const double dt = C.dt;
   // One gate for all the series evaluations of the knot: the tracking error (Log, then V^-1 and Q at its angle,
   // which the Log bounds cover) and the step rotation (V, Q, Exp at dt w).
@@ -675,7 +682,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
       double ed[12];
 #pragma unroll
       for (int a = 0; a < 6; a++) { ed[a] = e[a]; ed[6 + a] = ve[a]; }
-      rec_run<REC_D, 12>(P, i, b, ed);
+      rec_run<REC_D, 12, RP>(P, i, b, ed);
     }
     double We[6], W2v[6], l = 0;
 #pragma unroll
@@ -716,7 +723,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
           luu[a] = imu[a] + imu[M + a];
         }
       }
-      rec_run<REC_LU, M>(P, i, b, lu);
+      rec_run<REC_LU, M, RP>(P, i, b, lu);
       if (P.al_lb) {  // the field exists in AL solves only (Params::fLUU, even)
 #pragma unroll
         for (int k = 0; k < M; k += 2) {
@@ -753,8 +760,8 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
       lxv[a] = 2 * s;
       lxv[6 + a] = 2 * W2v[a];
     }
-    rec_run<REC_LXX, 21>(P, i, b, lxx);
-    rec_run<REC_LX, 12>(P, i, b, lxv);
+    rec_run<REC_LXX, 21, RP>(P, i, b, lxx);
+    rec_run<REC_LX, 12, RP>(P, i, b, lxv);
   }
   if (term) return;
   // ---------------- dynamics Jacobian blocks (traopt_dynamics.py:802-837, :1416-1469)
@@ -790,12 +797,12 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
 #pragma unroll
       for (int k = 18; k < 36; k++) P.REC[RIDX(i, k, b)] = blk[k];
     } else {
-      rec_run<0, 36>(P, i, b, blk);
+      rec_run<0, 36, RP>(P, i, b, blk);
     }
   }
   {
     const double xi6[6] = {S.w.x, S.v.x, S.w.y, S.v.y, S.w.z, S.v.z};  // (w_k, v_k) pairs: one 16-byte read each in k_backward3
-    rec_run<REC_XI, 6>(P, i, b, xi6);
+    rec_run<REC_XI, 6, RP>(P, i, b, xi6);
     if (P.fA22 >= 0) {  // kernel-uniform: the models whose backward sweep reads the block from the record
       double a22[36];
       a22_build(C, S.w, S.v, a22);
@@ -826,7 +833,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
       for (int k = 0; k < 9; k++) P.REC[RIDX(i, REC_BU + k, b)] = dt * Bu[k];
     }
     const double rt[3] = {rte.x, rte.y, rte.z};
-    rec_run<REC_LU + M, 3>(P, i, b, rt);
+    rec_run<REC_LU + M, 3, RP>(P, i, b, rt);
   }
   // ---------------- defect d = [Log(x_{i+1}^-1 f_q); f_xi - xi_{i+1}]  (traopt_controller.py:2882-2888)
   double d[12];
@@ -851,7 +858,7 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
 #pragma unroll
   for (int a = 0; a < 12; a++) d2 += d[a] * d[a];
   if (!(CLOSED && lcost)) {  // the fused launch neither stores nor sums a defect that is zero by construction
-    rec_run<REC_D, 12>(P, i, b, d);
+    rec_run<REC_D, 12, RP>(P, i, b, d);
     P.SD[(size_t)i * P.Bp + b] = d2;
   }
 }
@@ -860,7 +867,8 @@ TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots);  // (line-sea
 template <int M>
 __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
                                                     const double* __restrict__ src_u, double* __restrict__ dst,
-                                                    double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots) {
+                                                    double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots,
+                                                    int spec) {
   // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read.
   // ls_nslots > 0 (round 4): the candidates the LAST stage of a line search accepted are read where that stage left them -- slot
   // ls_slot[b], at the trajectory's position on the stage's list or at b (k_ls_copy's rule) -- instead of behind a copy into the
@@ -868,7 +876,17 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   const DConsts& C = *(const DConsts*)P.c;
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (size_t)ni * P.Bp) return;
-  const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
+  int b = (int)(t % P.Bp);
+  const int i = i0 + (int)(t / P.Bp);
+  if (spec) {
+    // behind a speculative first stage: only what that stage did not settle (list 2) -- by list position while the list is short
+    // (whole waves of work instead of a quarter of the lanes of every wave), by trajectory otherwise
+    const int n = P.ls_count[2];
+    if (2 * n <= P.Bp) {
+      if (b >= n) return;
+      b = P.ls_list[(size_t)2 * P.Bp + b];
+    } else if (P.ls_accept[b] == 0) return;
+  }
   if (!P.active[b]) return;
   int e = b;
   if (ls_nslots > 0) {
@@ -896,23 +914,27 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
 // also the on_iteration bookkeeping of traopt_controller.py:2621-2626
-__global__ void k_reduce(Params P, int it) {
+// spec: trajectories whose first step size was accepted have their cost from the speculative first stage (Jtrial[.][0])
+__global__ void k_reduce(Params P, int it, int spec = 0) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
+  const bool settled = spec && P.ls_accept[b] == 0;
   // fixed summation order (knot 0, 1, 2, ...); 64 waves cannot hide memory latency, so the loads go out
   // sixteen knots (32 loads) at a time
   double J = 0, d2 = 0;
   int i = 0;
-  for (; i + 16 <= P.N; i += 16) {
+  const int NN = settled ? 0 : P.N;  // (nothing to sum for a settled trajectory)
+  for (; i + 16 <= NN; i += 16) {
     double c[16], d[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { c[k] = P.SC[(size_t)(i + k) * P.Bp + b]; d[k] = P.SD[(size_t)(i + k) * P.Bp + b]; }
 #pragma unroll
     for (int k = 0; k < 16; k++) { J += c[k]; d2 += d[k]; }
   }
-  for (; i < P.N; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
+  for (; i < NN; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
   J += P.SC[(size_t)P.N * P.Bp + b];
   double dn = sqrt(d2);
+  if (settled) { J = P.Jtrial[(size_t)b * 20]; dn = 0.0; }
   P.Jc[b] = J;
   P.dn[b] = dn;
   if (b >= P.B) return;
@@ -2238,7 +2260,12 @@ TOLG_DEV State rl_in_state(const char* slot, int tt) {
 }
 template <int M>
 constexpr size_t rl_static_lds() { return (size_t)RL_DEPTH * RlIn<M>::SLOT + (size_t)RL_RING * RL_PAIRS * 256 + 32; }
-template <int M>
+// SPEC (round 4): the launch as the FIRST STAGE of a line search -- the step-size-1 candidate of both searches is this rollout
+// (single shooting: :2073-2080; merit search: the factors of :2713-2716 are the identity at alpha = 1) -- run speculatively: the
+// candidate goes to the candidate arrays, its cost to Jtrial[.][0] (defect norm 0), its records to P.REC, which the host points
+// at the OTHER record buffer (the search still reads this iteration's records), with a zero defect field when `it` (then: the
+// ms flag) is set; no bookkeeping.  A trajectory whose first step size is accepted is thereby already re-linearised.
+template <int M, bool SPEC = false>
 __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
   typedef RlIn<M> IN;
   const DConsts& C = *(const DConsts*)P.c;
@@ -2500,13 +2527,17 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 #pragma unroll
         for (int a = 0; a < M; a += 2) { const f64x2 w = pu[(a / 2) * 16]; u[a] = w.x; u[a + 1] = w.y; }
 #pragma unroll
-        for (int a = 0; a < M; a++) gst<TOLG_NT_CURST>(&P.cur_u[UIDX(a, i, b)], u[a]);
+        for (int a = 0; a < M; a++) gst<TOLG_NT_CURST>(&(SPEC ? P.cand_u : P.cur_u)[UIDX(a, i, b)], u[a]);
       }
-      if (i > 0) store_state<TOLG_NT_CURST>(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
+      if (SPEC || i > 0) store_state<TOLG_NT_CURST>(P, SPEC ? P.cand : P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
       // the terminal knot (in the last group only) goes separately: see lin_knot's TERM
       double lc = 0.0;
       if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
       if (4 * g + 3 >= N && i == N) lin_knot<M, true, 1>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
+      if (SPEC && it && i < N) {  // K2 reads the defect field of a merit-search solve: zero by construction here
+        const double z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        rec_run<REC_D, 12, TOLG_NT_RECST>(P, i, b, z);
+      }
       jpart += lc;
     }
     done++;
@@ -2531,6 +2562,11 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     for (int hh = 0; hh < RL_NH; hh++)
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) J += lpart[hh][k4][tt];
+    if (SPEC) {  // k_ls_sum's outputs for the first step size; the select decides
+      P.Jtrial[(size_t)b * 20] = J;
+      P.dtrial[(size_t)b * 20] = 0.0;
+      return;
+    }
     P.Jc[b] = J;
     P.dn[b] = 0.0;  // closed by construction
     if (b < P.B) {
@@ -2815,6 +2851,183 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
     store(i + 1);
   }
 }
+// ---- ... and the same rollouts in TWO wavefronts per sixteen quads (round 4).  A stage of the merit search that rolls out four
+// step sizes of the thousand trajectories the first one did not settle is 250 waves on 1024 SIMDs: its time is the length of
+// ONE dependent chain, 200 steps of ~2.9 us (k_rollout_ls) -- and a step's chain runs through two groups of transcendental
+// functions that do not depend on each other: the Log of the deviation from the nominal state (-> the control, -> the next
+// TWIST) and the Exp of the twist (-> the next POSE).  As in the fused launch (k_rollout_lin) one wavefront carries the twist
+// chain and a second one the pose chain, one step ahead, twist and pose handed over through a four-slot LDS ring; the merit
+// search's factors (roll_step's note: x_{i+1} Exp((alpha - 1) d_q) x_{i+1}^-1 on the pose, (alpha - 1) d_xi on the twist) are
+// functions of the nominal trajectory alone and are formed off the chain, while the wave waits for the other one.
+// Inputs come from HBM as in k_rollout_ls (gains requested at the top of a step, nominal state and defect a knot ahead): the
+// trajectories of a list are scattered over the batch, there is nothing for an LDS-DMA loader to stream.
+// Synchronisation: sync[0] = twists published (knots 0 .. sync[0]), sync[1] = poses published; data, then counter, by LDS
+// operations of one wave, which execute in order.  The twist wave's step i needs pose i (pose wave's step i - 1), the pose wave's
+// step i needs twist i (twist wave's step i - 1): each is at most one step ahead of the other, so a slot written at step i
+// (knot i + 1) replaces knot i - 3, which both have long read.  Every poll is bounded (TOLG_ST_INTERNAL instead of a hang).
+// FACT: the merit search's step for alpha < 1; otherwise x^+ = f(x^, u^) (single shooting, and alpha = 1 of both searches).
+enum { L2_RING = 4 };
+template <int M, bool FACT>
+__global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslots, int direct, int list) {
+  const DConsts& C = *(const DConsts*)P.c;
+  __shared__ __attribute__((aligned(16))) double ring[L2_RING][7 * 32];  // rl_put_pose / rl_put_twist layout, pairs 0..6
+  __shared__ int sync[2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 64 + lane, slot = blockIdx.y;
+  const int quad = t >> 2, q = t & 3, tt = lane >> 2;
+  if (slot >= nslots) return;
+  // (every return up to the barrier is taken by both waves or by neither: they map lanes to quads alike)
+  int b;
+  bool live;
+  if (list >= 0) {
+    const int n = P.ls_count[list];
+    if (n * nslots > LS_QUAD_MAX) return;  // the thread form's turn (ls_quad_form)
+    if ((quad & ~15) >= n) return;
+    live = quad < n;
+    b = P.ls_list[(size_t)list * P.Bp + (live ? quad : n - 1)];  // idle quads replay the last entry and store nothing
+  } else {
+    live = quad < P.Bp;
+    b = live ? quad : P.Bp - 1;
+    live = live && P.active[b] && P.ls_accept[b] < 0;  // (decided or finished trajectories compute along and store nothing)
+    if (!__any(live)) return;
+  }
+  if (threadIdx.x < 2) sync[threadIdx.x] = 0;
+  __syncthreads();
+  const rl_sync_t vsy = (rl_sync_t)sync;
+  const bool writer = live && q == 0;
+  const int N = P.N, ai = a0 + slot;
+  const double alpha = ls_alpha_k(ai), am1 = alpha - 1.0;
+  const unsigned sB = (unsigned)P.Bp * 8u, vb = (unsigned)b * 8u;
+  const unsigned vs = (list >= 0) ? (unsigned)(live ? quad : 0) * 8u : vb;  // where the candidate goes (k_rollout_ls)
+  const size_t stStride = (size_t)13 * P.Bp, uStride = (size_t)M * P.Bp, recStride = (size_t)P.recF * P.Bp;
+  double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
+  double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
+  const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
+  if (wave == 0) {
+    // ---------------- the twist chain: xi^_{i+1} from x^_i (pose from the other wave), u^_i on the way
+    State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);  // x^_0 = x_0
+    if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, Sn);
+    double dA[FACT ? 6 : 1], dB[FACT ? 6 : 1];
+    auto load_d = [&](int i, double (&d)[FACT ? 6 : 1]) {  // the twist half of the stored defect
+      if constexpr (FACT) {
+        __amdgpu_buffer_rsrc_t rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
+#pragma unroll
+        for (int a = 0; a < 6; a++) d[a] = bld(rR, REC_VR(b), FOFF(REC_D + 6 + a));
+      }
+    };
+    bool ok = true;
+    auto step = [&](int i, const State& So, const double (&d)[FACT ? 6 : 1]) {
+      RollIn<M> R;
+      roll_load<M, !FACT>(P, i, b, q, vb, sB, R);  // in flight while the pose arrives and Log runs
+      __builtin_amdgcn_sched_barrier(0);
+      if (i > 0) {
+        if (!rl_wait_ge(vsy + 1, i)) { ok = false; return; }
+        asm volatile("" ::: "memory");
+        Sn.X = rl_get_pose(ring[i % L2_RING], tt);
+      }
+      V3 ew, ev;
+      const Pose Dx = se3_compose(se3_inverse(So.X), Sn.X);
+      const double yl = quat_vec2(Dx.q);
+      se3_log_fast(Dx, ew, ev, series_gate(log_small(yl), log_dom(yl)));
+      const double e[12] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z, Sn.w.x - So.w.x, Sn.w.y - So.w.y, Sn.w.z - So.w.z,
+                            Sn.v.x - So.v.x, Sn.v.y - So.v.y, Sn.v.z - So.v.z};
+      double mine[2];
+#pragma unroll
+      for (int sidx = 0; sidx < 2; sidx++) {
+        double sacc = alpha * R.G[sidx][12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) sacc += R.G[sidx][k] * e[k];
+        mine[sidx] = sacc;
+      }
+      double un[M], du[M];
+      du[0] = quad_bcast<0>(mine[0]); du[1] = quad_bcast<0>(mine[1]);
+      du[2] = quad_bcast<1>(mine[0]); du[3] = quad_bcast<1>(mine[1]);
+      if constexpr (M == 6) { du[4] = quad_bcast<2>(mine[0]); du[5] = quad_bcast<2>(mine[1]); }
+#pragma unroll
+      for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
+      State Fn;
+      if (DK.diag) dyn_twist_k<M, DConsts, 0>(DK, C, Sn, un, Fn);
+      else Fn = dyn_f<M, DConsts, 0>(C, Sn, un);
+      if constexpr (FACT) {  // xi^_{i+1} = (alpha - 1) d_xi + f_xi(x^_i, u^_i)   (roll_step)
+        Sn.w = am1 * v3(d[0], d[1], d[2]) + Fn.w;
+        Sn.v = am1 * v3(d[3], d[4], d[5]) + Fn.v;
+      } else {
+        Sn.w = Fn.w;
+        Sn.v = Fn.v;
+      }
+      if (q == 0) rl_put_twist(ring[(i + 1) % L2_RING], tt, Sn.w, Sn.v);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) vsy[0] = i + 1;
+      if (writer) {  // u^_i and the twist of x^_{i+1} (its pose is the other wave's to store)
+        __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB), rSX = mkbuf(sx + stStride * (i + 1), 13 * sB);
+#pragma unroll
+        for (int a = 0; a < M; a++) bst(rSU, vs, a * sB, un[a]);
+        bst(rSX, vs, 7 * sB, Sn.w.x); bst(rSX, vs, 8 * sB, Sn.w.y); bst(rSX, vs, 9 * sB, Sn.w.z);
+        bst(rSX, vs, 10 * sB, Sn.v.x); bst(rSX, vs, 11 * sB, Sn.v.y); bst(rSX, vs, 12 * sB, Sn.v.z);
+      }
+    };
+    State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
+    load_d(0, dA);
+    for (int i = 0; ok && i < N; i += 2) {
+      if (i + 1 < N) { Sb = roll_load_state(P, i + 1, vb, sB); load_d(i + 1, dB); }
+      __builtin_amdgcn_sched_barrier(0);
+      step(i, Sa, dA);
+      if (!ok || i + 1 >= N) break;
+      if (i + 2 < N) { Sa = roll_load_state(P, i + 2, vb, sB); load_d(i + 2, dA); }
+      __builtin_amdgcn_sched_barrier(0);
+      step(i + 1, Sb, dB);
+    }
+    if (!ok && writer) P.status[b] = TOLG_ST_INTERNAL;
+    return;
+  }
+  // ---------------- the pose chain: X^_{i+1} = [M_i] project(X^_i Exp(xi^_i dt)), M_i = X_{i+1} Exp((alpha - 1) d_q) X_{i+1}^-1
+  State S = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  struct NomQ { Pose X; double d[6]; };
+  auto load_nom = [&](int i, NomQ& n) {  // pose of the nominal x_{i+1} and the pose half of the stored defect d_i
+    if constexpr (FACT) {
+      __amdgpu_buffer_rsrc_t rX = mkbuf(P.cur + stStride * (i + 1), 13 * sB), rR = mkbuf(P.REC + recStride * i, (unsigned)P.recF * sB);
+      n.X.q.x = bld(rX, vb, 0); n.X.q.y = bld(rX, vb, sB); n.X.q.z = bld(rX, vb, 2 * sB); n.X.q.w = bld(rX, vb, 3 * sB);
+      n.X.t = v3(bld(rX, vb, 4 * sB), bld(rX, vb, 5 * sB), bld(rX, vb, 6 * sB));
+#pragma unroll
+      for (int a = 0; a < 6; a++) n.d[a] = bld(rR, REC_VR(b), FOFF(REC_D + a));
+    }
+  };
+  NomQ nA, nB;
+  load_nom(0, nA);
+  bool ok = true;
+  auto pstep = [&](int i, const NomQ& n) {
+    Pose Mx;
+    if constexpr (FACT)
+      Mx = se3_compose(se3_compose(n.X, se3_exp_fast(am1 * v3(n.d[0], n.d[1], n.d[2]), am1 * v3(n.d[3], n.d[4], n.d[5]))), se3_inverse(n.X));
+    if (i > 0) {
+      if (!rl_wait_ge(vsy, i)) { ok = false; return; }
+      asm volatile("" ::: "memory");
+      rl_get_twist(ring[i % L2_RING], tt, S.w, S.v);
+    }
+    Pose F = dyn_pose_k(DK, S);
+    if constexpr (FACT) F = se3_project(se3_compose(Mx, F));
+    S.X = F;
+    if (q == 0) rl_put_pose(ring[(i + 1) % L2_RING], tt, S.X);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) vsy[1] = i + 1;
+    if (writer) {
+      __amdgpu_buffer_rsrc_t rSX = mkbuf(sx + stStride * (i + 1), 13 * sB);
+      bst(rSX, vs, 0, S.X.q.x); bst(rSX, vs, sB, S.X.q.y); bst(rSX, vs, 2 * sB, S.X.q.z); bst(rSX, vs, 3 * sB, S.X.q.w);
+      bst(rSX, vs, 4 * sB, S.X.t.x); bst(rSX, vs, 5 * sB, S.X.t.y); bst(rSX, vs, 6 * sB, S.X.t.z);
+    }
+  };
+  for (int i = 0; ok && i < N; i += 2) {
+    if (i + 1 < N) load_nom(i + 1, nB);
+    __builtin_amdgcn_sched_barrier(0);
+    pstep(i, nA);
+    if (!ok || i + 1 >= N) break;
+    if (i + 2 < N) load_nom(i + 2, nA);
+    __builtin_amdgcn_sched_barrier(0);
+    pstep(i + 1, nB);
+  }
+}
 // stage cost l(x^_i, u^_i) (traopt_cost.py:675-738) and, MS, the squared defect
 // |Log(x^_{i+1}^-1 f_q(x^_i, u^_i))|^2 + |f_xi - xi^_{i+1}|^2 (:2790-2812) of every stored candidate of the stage
 template <int M, bool MS>
@@ -3059,7 +3272,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
 
 __global__ void k_ls_begin(Params P, int first_fit_iteration) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < 2) P.ls_count[b] = 0;
+  if (b < 3) P.ls_count[b] = 0;
   if (b >= P.Bp) return;
   P.ls_accept[b] = -1;
   P.ls_slot[b] = -1;
@@ -3070,7 +3283,7 @@ __global__ void k_ls_begin(Params P, int first_fit_iteration) {
 // first alpha (in the reference's order) of this stage that passes the acceptance test
 // ... and the trajectories that stay undecided go on list `out` (compacted, for the next stage's rollouts)
 template <bool MS>
-__global__ void k_ls_select(Params P, int a0, int nslots, int out) {
+__global__ void k_ls_select(Params P, int a0, int nslots, int out, int out2 = -1) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b] || P.ls_accept[b] >= 0) return;
   const double J0 = P.Jc[b], dn = P.dn[b];
@@ -3087,13 +3300,18 @@ __global__ void k_ls_select(Params P, int a0, int nslots, int out) {
     } else {
       ok = Jn < J0;
     }
-    if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = s; return; }
+    // (out2 >= 0: the speculative first stage -- its candidate is in the candidate arrays, not in a slot)
+    if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = out2 >= 0 ? -1 : s; return; }
   }
   // (an ordered compaction -- one workgroup, a scan -- instead of the counter was measured: no gain, 405 -> 395 it/s;
   // waves take their turns at the counter nearly in order as it is)
   const int pos = atomicAdd(&P.ls_count[out], 1);
   P.ls_list[(size_t)out * P.Bp + pos] = b;
   P.ls_pos[(size_t)out * P.Bp + b] = pos;
+  if (out2 >= 0) {  // a second copy that outlives the stages (list `out` is recycled two stages on)
+    P.ls_list[(size_t)out2 * P.Bp + pos] = b;
+    atomicAdd(&P.ls_count[out2], 1);
+  }
 }
 
 // the accepted candidate of a wide stage -> the candidate arrays.  list / nslots: the stage's list and width -- the quad
@@ -3112,6 +3330,21 @@ __global__ void k_ls_copy(Params P, int list, int nslots) {
   for (int c = 0; c < 13; c++) P.cand[SIDX(c, i, b)] = sx[SIDX(c, i, e)];
   if (i < P.N)
     for (int c = 0; c < P.m; c++) P.cand_u[UIDX(c, i, b)] = su[UIDX(c, i, e)];
+}
+// what the speculative first stage settled (first step size accepted): candidate arrays -> nominal trajectory (everything else
+// is copied by the re-linearisation while it reads)
+__global__ void k_spec_commit(Params P) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(P.N + 1) * P.Bp) return;
+  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
+  if (!P.active[b] || P.ls_accept[b] != 0) return;
+  double x[13];
+#pragma unroll
+  for (int c = 0; c < 13; c++) x[c] = P.cand[SIDX(c, i, b)];
+#pragma unroll
+  for (int c = 0; c < 13; c++) P.cur[SIDX(c, i, b)] = x[c];
+  if (i < P.N)
+    for (int c = 0; c < P.m; c++) P.cur_u[UIDX(c, i, b)] = P.cand_u[UIDX(c, i, b)];
 }
 __global__ void k_ls_clear_slot(Params P, int reset_list) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3446,14 +3679,15 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* k2_redo = c.take<int>(B / 4 + 1);
   int* k2_hint = c.take<int>(B / 4 + 1);
   int* ec_redo = c.take<int>(B);
-  int* ls_list = c.take<int>(2 * B);
+  int* ls_list = c.take<int>(3 * B);
   int* ls_count = c.take<int>(64);
-  int* ls_pos = c.take<int>(2 * B);
+  int* ls_pos = c.take<int>(3 * B);
+  double* REC2 = c.take<double>((N + 1) * (size_t)REC_FMAX * B);
   double* LSC = c.take<double>((size_t)NSLOT * (N + 1) * B);
   double* LSD = c.take<double>((size_t)NSLOT * N * B);
   double* ED = c.take<double>((N + 1) * 32 * B);
   if (P) {
-    P->ED = ED; P->affine = 0; P->pad3 = 0;
+    P->ED = ED; P->affine = 0; P->pad3 = 0; P->REC2 = REC2;
     P->k2_redo = k2_redo; P->k2_hint = k2_hint;
     P->ec_redo = ec_redo;
     P->ls_list = ls_list; P->ls_count = ls_count; P->ls_pos = ls_pos; P->LSC = LSC; P->LSD = LSD;
@@ -3708,13 +3942,38 @@ static Params params_for(tolg_handle_s* h, int B) {
 
 template <int M>
 static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, const double* src, const double* src_u,
-                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1, int ls_list = -1, int ls_nslots = 0) {
+                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1, int ls_list = -1, int ls_nslots = 0,
+                         int spec = 0) {
   if (ni < 0) ni = P.N + 1;
   size_t n = (size_t)ni * P.Bp;
   h->rec_closed = 0;  // K1 writes the defect field
   Timed t(h, st, 2);
   hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms,
-                     i0, ni, ls_list, ls_nslots);
+                     i0, ni, ls_list, ls_nslots, spec);
+  LAUNCH_CHECK();
+  return 0;
+}
+// May the first stage of a line search be the fused launch, run speculatively (k_rollout_lin<M, true>)?  Where the fused launch
+// itself may run (iterate_ms) -- and only on request (TOLG_LS_SPEC=1): measured SLOWER than the staged first try in both searches
+// (merit 545 -> 489 it/s, SS 449 -> 425: the launch shares the chip with the expected-change kernel, whose waves cannot sit on a
+// SIMD beside its own -- 414 + 365 registers --, and the re-linearisation of the quarter of the batch it does not settle costs
+// as much as that of the whole batch: scattered trajectories touch the same lines).
+template <int M>
+static bool ls_spec_ok(const tolg_handle_s* h, const Params& P, const tolg_options* opt) {
+  return !opt->rollout_linear && !P.affine && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT &&
+         rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block && getenv_flag("TOLG_LS_SPEC");
+}
+// ... the stage itself: the launch (records into the other buffer: Pw), then the select, which also keeps the list of the
+// trajectories the stage did not settle (list 2) for the re-linearisation
+template <int M, bool MS>
+static int run_ls_spec_stage(tolg_handle_s* h, const Params& P, const Params& Pw, hipStream_t st, hipEvent_t before_select) {
+  {
+    Timed t(h, st, 1, true);
+    t.launch(k_rollout_lin<M, true>, dim3((P.Bp + 15) / 16), dim3(256), Pw, MS ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
+  hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0, 1, 0, 2);
   LAUNCH_CHECK();
   return 0;
 }
@@ -3815,7 +4074,10 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   // factors of :2713-2716 are the identity: note at the record layout) -- K3 itself, written straight into the candidate
   // arrays (every active trajectory is undecided at this point)
   const bool k3 = direct && a0 == 0 && !linear;
-  if (k3) {
+  // the rollouts of a stage in two wavefronts per sixteen quads (k_rollout_ls2): the nonlinear rollouts of every model but the
+  // pendulum; TOLG_LS_ONEWAVE=1 keeps the one-wave forms (K3 for the first try, k_rollout_ls) for comparisons
+  const bool two = !linear && !pend && !getenv_flag("TOLG_LS_ONEWAVE");
+  if (k3 && !two) {
     int rc = run_rollout_ms<M>(h, P, st, 1.0, 0, MS ? 1 : 0);
     if (rc) return rc;
   }
@@ -3829,7 +4091,10 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
     }
     {
       dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per (trajectory, alpha)
-      if (k3) {
+      if (two) {
+        if (MS && !k3) hipLaunchKernelGGL((k_rollout_ls2<M, true>), grid, dim3(128), 0, st, P, a0, n, direct, list_in);
+        else hipLaunchKernelGGL((k_rollout_ls2<M, false>), grid, dim3(128), 0, st, P, a0, n, direct, list_in);
+      } else if (k3) {
       } else if (pend) {
         if (linear) hipLaunchKernelGGL((k_rollout_ls<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
         else hipLaunchKernelGGL((k_rollout_ls<6, MS, false, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
@@ -3877,10 +4142,14 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
 
 // iLQR_Tracking_SE3_MS loop body (traopt_controller.py:2522-2626)
 template <int M>
-static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+static int iterate_ms(tolg_handle_s* h, Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     int ls_list_last = -1, ls_n_last = 0;  // set by the merit search below: where its last stage left what it accepted
+    // a search with a speculative first stage writes the next iteration's records into the other buffer (Pw)
+    const bool spec = opt->line_search && ls_spec_ok<M>(h, P, opt);
+    Params Pw = P;
+    if (spec) Pw.REC = P.REC2;
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
     if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
         opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block) {
@@ -3950,7 +4219,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       // (the first TWO step sizes in the first stage -- most trajectories that reject the first accept the second -- was
       // measured: 432 -> 387 it/s; 512 rollout waves of the general MS step beside the expected-change kernel cost more
       // than the nearly empty second stage saves)
-      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
+      if (spec) { if ((rc = run_ls_spec_stage<M, true>(h, P, Pw, st, h->side_ev[1]))) return rc; }
+      else if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
       // (round 4: 1 + 12 + 7 instead of 1 + 4 + 8 + 7 -- one latency chain fewer -- measured: 455 -> 418 it/s; the twelve-wide
       // stage rolls out eight step sizes nobody needed for most of its trajectories)
       // (the last stage leaves what it accepted in its slots: the re-linearisation reads it there)
@@ -3964,10 +4234,18 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       ls_list_last = so3f ? 1 : 0;   // the list the last stage ran on: (stage - 1) & 1
       ls_n_last = so3f ? 8 : 7;
     }
-    // the accepted candidate becomes the nominal trajectory while it is re-linearised
-    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last))) return rc;
-    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+    // the accepted candidate becomes the nominal trajectory while it is re-linearised (what the speculative stage settled is
+    // re-linearised already: its candidate is copied, its records are in the other buffer, which becomes THE buffer)
+    if (spec) {
+      const size_t nn = (size_t)(P.N + 1) * P.Bp;
+      Timed t(h, st, 2);
+      hipLaunchKernelGGL(k_spec_commit, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
+      LAUNCH_CHECK();
+    }
+    if ((rc = run_linearize<M>(h, Pw, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last, spec))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it, spec ? 1 : 0);
     LAUNCH_CHECK();
+    if (spec) { double* r = P.REC; P.REC = P.REC2; P.REC2 = r; }
   }
   return 0;
 }
@@ -3975,14 +4253,18 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
 // iLQR_Tracking_SE3 loop body (traopt_controller.py:1926-2007): gradient test and backward pass share
 // one sweep; 13-alpha backtracking in two speculative stages (the first try, then the other twelve)
 template <int M>
-static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+static int iterate_ss(tolg_handle_s* h, Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
+    const bool spec = ls_spec_ok<M>(h, P, opt);  // (iterate_ms)
+    Params Pw = P;
+    if (spec) Pw.REC = P.REC2;
     if ((rc = run_backward<M>(h, P, st, it, 0))) return rc;
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
     if (P.affine && (rc = run_affine_dev<M>(h, P, st, false))) return rc;
-    if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
+    if (spec) { if ((rc = run_ls_spec_stage<M, false>(h, P, Pw, st, nullptr))) return rc; }
+    else if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
     // (1 + 4 + 8 like the merit search was measured: 405 -> 339 it/s on iterations 3..23 of the benchmark solve, whose
     // searches end at the 6th to 10th step size -- tools/ls_alpha_histogram.py; it would pay from iteration ~45 on, where
     // the median accepted step size is the second one)
@@ -3991,9 +4273,16 @@ static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt
     LAUNCH_CHECK();
     // (what the twelve-alpha stage accepted is read from its slots -- no k_ls_copy: 0.15-0.2 ms of a 2.4 ms iteration; on the
     // affine path the candidates are in the candidate arrays, where k_affine_commit wrote them)
-    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0, 0, -1, 0, P.affine ? 0 : NALPHA_SS - 1))) return rc;
-    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
+    if (spec) {
+      const size_t nn = (size_t)(P.N + 1) * P.Bp;
+      Timed t(h, st, 2);
+      hipLaunchKernelGGL(k_spec_commit, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
+      LAUNCH_CHECK();
+    }
+    if ((rc = run_linearize<M>(h, Pw, st, P.cand, P.cand_u, P.cur, P.cur_u, 0, 0, -1, 0, P.affine ? 0 : NALPHA_SS - 1, spec))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it, spec ? 1 : 0);
     LAUNCH_CHECK();
+    if (spec) { double* r = P.REC; P.REC = P.REC2; P.REC2 = r; }
   }
   return 0;
 }
@@ -4021,6 +4310,11 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
     if (P.m == 4) hipLaunchKernelGGL(k_init_rollout<4>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
     else hipLaunchKernelGGL(k_init_rollout<6>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
     LAUNCH_CHECK();
+  }
+  if (opt->line_search || !ms) {
+    // the other record buffer of a search with a speculative first stage: K2 loads the records of a whole group of four, also
+    // of its inactive trajectories (whose lanes it ignores) -- those must be numbers, not what the workspace happened to hold
+    if (hipMemsetAsync(P.REC2, 0, sizeof(double) * (size_t)(P.N + 1) * P.recF * P.Bp, st) != hipSuccess) return TOLG_E_LAUNCH;
   }
   int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms)
                       : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms);
