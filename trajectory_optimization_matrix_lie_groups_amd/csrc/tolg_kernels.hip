@@ -147,12 +147,9 @@ struct Params {
   int affine, pad3;    // this solve takes its linear-rollout candidates from ED (every trajectory with ec_redo == 0)
   // line search, round 3 form: the stages roll out only (quad rollouts over a compacted list of the undecided
   // trajectories), costs and defects of the candidates are evaluated in parallel over the knots
-  int* ls_list;        // [3][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
-  int* ls_count;       // [3]      ... the stage's kernels still read the current one; list 2: the trajectories the speculative
-                       //          first stage (k_rollout_lin<M, true>) did NOT settle, kept until the re-linearisation
-  int* ls_pos;         // [3][Bp]  position of a trajectory on its list: the quad form keeps a stage's candidates densely, by position
-  double* REC2;        // the other record buffer of a line-search solve: the speculative first stage and the re-linearisation
-                       // write the NEXT iteration's records there while the search still reads this iteration's (host swaps)
+  int* ls_list;        // [2][Bp]  undecided trajectories after a stage (two lists: a select builds the next while ...)
+  int* ls_count;       // [2]      ... the stage's kernels still read the current one
+  int* ls_pos;         // [2][Bp]  position of a trajectory on its list: the quad form keeps a stage's candidates densely, by position
   double* LSC;         // [NSLOT][N+1][Bp] stage costs of the candidates
   double* LSD;         // [NSLOT][N][Bp]   squared defects of the candidates (MS)
   // augmented-Lagrangian box input constraint (ALConstrainedCost + InputConstraint), caller-owned
@@ -867,8 +864,7 @@ TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots);  // (line-sea
 template <int M>
 __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
                                                     const double* __restrict__ src_u, double* __restrict__ dst,
-                                                    double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots,
-                                                    int spec) {
+                                                    double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots) {
   // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read.
   // ls_nslots > 0 (round 4): the candidates the LAST stage of a line search accepted are read where that stage left them -- slot
   // ls_slot[b], at the trajectory's position on the stage's list or at b (k_ls_copy's rule) -- instead of behind a copy into the
@@ -876,17 +872,7 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
   const DConsts& C = *(const DConsts*)P.c;
   size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (size_t)ni * P.Bp) return;
-  int b = (int)(t % P.Bp);
-  const int i = i0 + (int)(t / P.Bp);
-  if (spec) {
-    // behind a speculative first stage: only what that stage did not settle (list 2) -- by list position while the list is short
-    // (whole waves of work instead of a quarter of the lanes of every wave), by trajectory otherwise
-    const int n = P.ls_count[2];
-    if (2 * n <= P.Bp) {
-      if (b >= n) return;
-      b = P.ls_list[(size_t)2 * P.Bp + b];
-    } else if (P.ls_accept[b] == 0) return;
-  }
+  const int b = (int)(t % P.Bp), i = i0 + (int)(t / P.Bp);
   if (!P.active[b]) return;
   int e = b;
   if (ls_nslots > 0) {
@@ -914,27 +900,23 @@ __global__ __launch_bounds__(256) void k_linearize(Params P, const double* __res
 
 // per-trajectory sums of the stage costs / squared defects, fixed order (deterministic);
 // also the on_iteration bookkeeping of traopt_controller.py:2621-2626
-// spec: trajectories whose first step size was accepted have their cost from the speculative first stage (Jtrial[.][0])
-__global__ void k_reduce(Params P, int it, int spec = 0) {
+__global__ void k_reduce(Params P, int it) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b]) return;
-  const bool settled = spec && P.ls_accept[b] == 0;
   // fixed summation order (knot 0, 1, 2, ...); 64 waves cannot hide memory latency, so the loads go out
   // sixteen knots (32 loads) at a time
   double J = 0, d2 = 0;
   int i = 0;
-  const int NN = settled ? 0 : P.N;  // (nothing to sum for a settled trajectory)
-  for (; i + 16 <= NN; i += 16) {
+  for (; i + 16 <= P.N; i += 16) {
     double c[16], d[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { c[k] = P.SC[(size_t)(i + k) * P.Bp + b]; d[k] = P.SD[(size_t)(i + k) * P.Bp + b]; }
 #pragma unroll
     for (int k = 0; k < 16; k++) { J += c[k]; d2 += d[k]; }
   }
-  for (; i < NN; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
+  for (; i < P.N; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
   J += P.SC[(size_t)P.N * P.Bp + b];
   double dn = sqrt(d2);
-  if (settled) { J = P.Jtrial[(size_t)b * 20]; dn = 0.0; }
   P.Jc[b] = J;
   P.dn[b] = dn;
   if (b >= P.B) return;
@@ -2260,12 +2242,7 @@ TOLG_DEV State rl_in_state(const char* slot, int tt) {
 }
 template <int M>
 constexpr size_t rl_static_lds() { return (size_t)RL_DEPTH * RlIn<M>::SLOT + (size_t)RL_RING * RL_PAIRS * 256 + 32; }
-// SPEC (round 4): the launch as the FIRST STAGE of a line search -- the step-size-1 candidate of both searches is this rollout
-// (single shooting: :2073-2080; merit search: the factors of :2713-2716 are the identity at alpha = 1) -- run speculatively: the
-// candidate goes to the candidate arrays, its cost to Jtrial[.][0] (defect norm 0), its records to P.REC, which the host points
-// at the OTHER record buffer (the search still reads this iteration's records), with a zero defect field when `it` (then: the
-// ms flag) is set; no bookkeeping.  A trajectory whose first step size is accepted is thereby already re-linearised.
-template <int M, bool SPEC = false>
+template <int M>
 __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
   typedef RlIn<M> IN;
   const DConsts& C = *(const DConsts*)P.c;
@@ -2527,17 +2504,13 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
 #pragma unroll
         for (int a = 0; a < M; a += 2) { const f64x2 w = pu[(a / 2) * 16]; u[a] = w.x; u[a + 1] = w.y; }
 #pragma unroll
-        for (int a = 0; a < M; a++) gst<TOLG_NT_CURST>(&(SPEC ? P.cand_u : P.cur_u)[UIDX(a, i, b)], u[a]);
+        for (int a = 0; a < M; a++) gst<TOLG_NT_CURST>(&P.cur_u[UIDX(a, i, b)], u[a]);
       }
-      if (SPEC || i > 0) store_state<TOLG_NT_CURST>(P, SPEC ? P.cand : P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
+      if (i > 0) store_state<TOLG_NT_CURST>(P, P.cur, i, b, S);  // the accepted candidate becomes the nominal trajectory
       // the terminal knot (in the last group only) goes separately: see lin_knot's TERM
       double lc = 0.0;
       if (i < N) lin_knot<M, true, 0>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
       if (4 * g + 3 >= N && i == N) lin_knot<M, true, 1>(P, C, i, b, 1, S, u, [&]() { return S; }, &lc);
-      if (SPEC && it && i < N) {  // K2 reads the defect field of a merit-search solve: zero by construction here
-        const double z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        rec_run<REC_D, 12, TOLG_NT_RECST>(P, i, b, z);
-      }
       jpart += lc;
     }
     done++;
@@ -2562,11 +2535,6 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     for (int hh = 0; hh < RL_NH; hh++)
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) J += lpart[hh][k4][tt];
-    if (SPEC) {  // k_ls_sum's outputs for the first step size; the select decides
-      P.Jtrial[(size_t)b * 20] = J;
-      P.dtrial[(size_t)b * 20] = 0.0;
-      return;
-    }
     P.Jc[b] = J;
     P.dn[b] = 0.0;  // closed by construction
     if (b < P.B) {
@@ -3272,7 +3240,7 @@ __global__ __launch_bounds__(64) void k_expected_change(Params P) {
 
 __global__ void k_ls_begin(Params P, int first_fit_iteration) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < 3) P.ls_count[b] = 0;
+  if (b < 2) P.ls_count[b] = 0;
   if (b >= P.Bp) return;
   P.ls_accept[b] = -1;
   P.ls_slot[b] = -1;
@@ -3283,7 +3251,7 @@ __global__ void k_ls_begin(Params P, int first_fit_iteration) {
 // first alpha (in the reference's order) of this stage that passes the acceptance test
 // ... and the trajectories that stay undecided go on list `out` (compacted, for the next stage's rollouts)
 template <bool MS>
-__global__ void k_ls_select(Params P, int a0, int nslots, int out, int out2 = -1) {
+__global__ void k_ls_select(Params P, int a0, int nslots, int out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.Bp || !P.active[b] || P.ls_accept[b] >= 0) return;
   const double J0 = P.Jc[b], dn = P.dn[b];
@@ -3300,18 +3268,13 @@ __global__ void k_ls_select(Params P, int a0, int nslots, int out, int out2 = -1
     } else {
       ok = Jn < J0;
     }
-    // (out2 >= 0: the speculative first stage -- its candidate is in the candidate arrays, not in a slot)
-    if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = out2 >= 0 ? -1 : s; return; }
+    if (ok) { P.ls_accept[b] = ai; P.ls_slot[b] = s; return; }
   }
   // (an ordered compaction -- one workgroup, a scan -- instead of the counter was measured: no gain, 405 -> 395 it/s;
   // waves take their turns at the counter nearly in order as it is)
   const int pos = atomicAdd(&P.ls_count[out], 1);
   P.ls_list[(size_t)out * P.Bp + pos] = b;
   P.ls_pos[(size_t)out * P.Bp + b] = pos;
-  if (out2 >= 0) {  // a second copy that outlives the stages (list `out` is recycled two stages on)
-    P.ls_list[(size_t)out2 * P.Bp + pos] = b;
-    atomicAdd(&P.ls_count[out2], 1);
-  }
 }
 
 // the accepted candidate of a wide stage -> the candidate arrays.  list / nslots: the stage's list and width -- the quad
@@ -3330,21 +3293,6 @@ __global__ void k_ls_copy(Params P, int list, int nslots) {
   for (int c = 0; c < 13; c++) P.cand[SIDX(c, i, b)] = sx[SIDX(c, i, e)];
   if (i < P.N)
     for (int c = 0; c < P.m; c++) P.cand_u[UIDX(c, i, b)] = su[UIDX(c, i, e)];
-}
-// what the speculative first stage settled (first step size accepted): candidate arrays -> nominal trajectory (everything else
-// is copied by the re-linearisation while it reads)
-__global__ void k_spec_commit(Params P) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)(P.N + 1) * P.Bp) return;
-  const int b = (int)(t % P.Bp), i = (int)(t / P.Bp);
-  if (!P.active[b] || P.ls_accept[b] != 0) return;
-  double x[13];
-#pragma unroll
-  for (int c = 0; c < 13; c++) x[c] = P.cand[SIDX(c, i, b)];
-#pragma unroll
-  for (int c = 0; c < 13; c++) P.cur[SIDX(c, i, b)] = x[c];
-  if (i < P.N)
-    for (int c = 0; c < P.m; c++) P.cur_u[UIDX(c, i, b)] = P.cand_u[UIDX(c, i, b)];
 }
 __global__ void k_ls_clear_slot(Params P, int reset_list) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3679,15 +3627,14 @@ static size_t carve_all(const tolg_problem* pr, int Bp, char* base, Params* P, C
   int* k2_redo = c.take<int>(B / 4 + 1);
   int* k2_hint = c.take<int>(B / 4 + 1);
   int* ec_redo = c.take<int>(B);
-  int* ls_list = c.take<int>(3 * B);
+  int* ls_list = c.take<int>(2 * B);
   int* ls_count = c.take<int>(64);
-  int* ls_pos = c.take<int>(3 * B);
-  double* REC2 = c.take<double>((N + 1) * (size_t)REC_FMAX * B);
+  int* ls_pos = c.take<int>(2 * B);
   double* LSC = c.take<double>((size_t)NSLOT * (N + 1) * B);
   double* LSD = c.take<double>((size_t)NSLOT * N * B);
   double* ED = c.take<double>((N + 1) * 32 * B);
   if (P) {
-    P->ED = ED; P->affine = 0; P->pad3 = 0; P->REC2 = REC2;
+    P->ED = ED; P->affine = 0; P->pad3 = 0;
     P->k2_redo = k2_redo; P->k2_hint = k2_hint;
     P->ec_redo = ec_redo;
     P->ls_list = ls_list; P->ls_count = ls_count; P->ls_pos = ls_pos; P->LSC = LSC; P->LSD = LSD;
@@ -3942,38 +3889,13 @@ static Params params_for(tolg_handle_s* h, int B) {
 
 template <int M>
 static int run_linearize(tolg_handle_s* h, const Params& P, hipStream_t st, const double* src, const double* src_u,
-                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1, int ls_list = -1, int ls_nslots = 0,
-                         int spec = 0) {
+                         double* dst, double* dst_u, int ms, int i0 = 0, int ni = -1, int ls_list = -1, int ls_nslots = 0) {
   if (ni < 0) ni = P.N + 1;
   size_t n = (size_t)ni * P.Bp;
   h->rec_closed = 0;  // K1 writes the defect field
   Timed t(h, st, 2);
   hipLaunchKernelGGL(k_linearize<M>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, src, src_u, dst, dst_u, ms,
-                     i0, ni, ls_list, ls_nslots, spec);
-  LAUNCH_CHECK();
-  return 0;
-}
-// May the first stage of a line search be the fused launch, run speculatively (k_rollout_lin<M, true>)?  Where the fused launch
-// itself may run (iterate_ms) -- and only on request (TOLG_LS_SPEC=1): measured SLOWER than the staged first try in both searches
-// (merit 545 -> 489 it/s, SS 449 -> 425: the launch shares the chip with the expected-change kernel, whose waves cannot sit on a
-// SIMD beside its own -- 414 + 365 registers --, and the re-linearisation of the quarter of the batch it does not settle costs
-// as much as that of the whole batch: scattered trajectories touch the same lines).
-template <int M>
-static bool ls_spec_ok(const tolg_handle_s* h, const Params& P, const tolg_options* opt) {
-  return !opt->rollout_linear && !P.affine && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT &&
-         rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block && getenv_flag("TOLG_LS_SPEC");
-}
-// ... the stage itself: the launch (records into the other buffer: Pw), then the select, which also keeps the list of the
-// trajectories the stage did not settle (list 2) for the re-linearisation
-template <int M, bool MS>
-static int run_ls_spec_stage(tolg_handle_s* h, const Params& P, const Params& Pw, hipStream_t st, hipEvent_t before_select) {
-  {
-    Timed t(h, st, 1, true);
-    t.launch(k_rollout_lin<M, true>, dim3((P.Bp + 15) / 16), dim3(256), Pw, MS ? 1 : 0);
-    LAUNCH_CHECK();
-  }
-  if (before_select && hipStreamWaitEvent(st, before_select, 0) != hipSuccess) return TOLG_E_LAUNCH;
-  hipLaunchKernelGGL((k_ls_select<MS>), dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0, 1, 0, 2);
+                     i0, ni, ls_list, ls_nslots);
   LAUNCH_CHECK();
   return 0;
 }
@@ -4142,14 +4064,10 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
 
 // iLQR_Tracking_SE3_MS loop body (traopt_controller.py:2522-2626)
 template <int M>
-static int iterate_ms(tolg_handle_s* h, Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
     int ls_list_last = -1, ls_n_last = 0;  // set by the merit search below: where its last stage left what it accepted
-    // a search with a speculative first stage writes the next iteration's records into the other buffer (Pw)
-    const bool spec = opt->line_search && ls_spec_ok<M>(h, P, opt);
-    Params Pw = P;
-    if (spec) Pw.REC = P.REC2;
     if ((rc = run_backward<M>(h, P, st, it, 1))) return rc;
     if (!opt->line_search && !opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D &&
         opt->schedule != TOLG_SCHED_SPLIT && rl_static_lds<M>() + sizeof(double) * RL_NH * 4 * 16 <= (size_t)h->lds_per_block) {
@@ -4219,8 +4137,7 @@ static int iterate_ms(tolg_handle_s* h, Params& P, const tolg_options* opt, hipS
       // (the first TWO step sizes in the first stage -- most trajectories that reject the first accept the second -- was
       // measured: 432 -> 387 it/s; 512 rollout waves of the general MS step beside the expected-change kernel cost more
       // than the nearly empty second stage saves)
-      if (spec) { if ((rc = run_ls_spec_stage<M, true>(h, P, Pw, st, h->side_ev[1]))) return rc; }
-      else if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
+      if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, opt->rollout_linear, h->side_ev[1]))) return rc;
       // (round 4: 1 + 12 + 7 instead of 1 + 4 + 8 + 7 -- one latency chain fewer -- measured: 455 -> 418 it/s; the twelve-wide
       // stage rolls out eight step sizes nobody needed for most of its trajectories)
       // (the last stage leaves what it accepted in its slots: the re-linearisation reads it there)
@@ -4234,18 +4151,10 @@ static int iterate_ms(tolg_handle_s* h, Params& P, const tolg_options* opt, hipS
       ls_list_last = so3f ? 1 : 0;   // the list the last stage ran on: (stage - 1) & 1
       ls_n_last = so3f ? 8 : 7;
     }
-    // the accepted candidate becomes the nominal trajectory while it is re-linearised (what the speculative stage settled is
-    // re-linearised already: its candidate is copied, its records are in the other buffer, which becomes THE buffer)
-    if (spec) {
-      const size_t nn = (size_t)(P.N + 1) * P.Bp;
-      Timed t(h, st, 2);
-      hipLaunchKernelGGL(k_spec_commit, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
-      LAUNCH_CHECK();
-    }
-    if ((rc = run_linearize<M>(h, Pw, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last, spec))) return rc;
-    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it, spec ? 1 : 0);
+    // the accepted candidate becomes the nominal trajectory while it is re-linearised
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
-    if (spec) { double* r = P.REC; P.REC = P.REC2; P.REC2 = r; }
   }
   return 0;
 }
@@ -4253,18 +4162,14 @@ static int iterate_ms(tolg_handle_s* h, Params& P, const tolg_options* opt, hipS
 // iLQR_Tracking_SE3 loop body (traopt_controller.py:1926-2007): gradient test and backward pass share
 // one sweep; 13-alpha backtracking in two speculative stages (the first try, then the other twelve)
 template <int M>
-static int iterate_ss(tolg_handle_s* h, Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
+static int iterate_ss(tolg_handle_s* h, const Params& P, const tolg_options* opt, hipStream_t st, int it0, int n) {
   int rc;
   for (int it = it0; it < it0 + n; it++) {
-    const bool spec = ls_spec_ok<M>(h, P, opt);  // (iterate_ms)
-    Params Pw = P;
-    if (spec) Pw.REC = P.REC2;
     if ((rc = run_backward<M>(h, P, st, it, 0))) return rc;
     hipLaunchKernelGGL(k_ls_begin, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, 0);
     LAUNCH_CHECK();
     if (P.affine && (rc = run_affine_dev<M>(h, P, st, false))) return rc;
-    if (spec) { if ((rc = run_ls_spec_stage<M, false>(h, P, Pw, st, nullptr))) return rc; }
-    else if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
+    if ((rc = run_ls_stage<M, false>(h, P, st, 0, 0, 1, opt->rollout_linear))) return rc;
     // (1 + 4 + 8 like the merit search was measured: 405 -> 339 it/s on iterations 3..23 of the benchmark solve, whose
     // searches end at the 6th to 10th step size -- tools/ls_alpha_histogram.py; it would pay from iteration ~45 on, where
     // the median accepted step size is the second one)
@@ -4273,16 +4178,9 @@ static int iterate_ss(tolg_handle_s* h, Params& P, const tolg_options* opt, hipS
     LAUNCH_CHECK();
     // (what the twelve-alpha stage accepted is read from its slots -- no k_ls_copy: 0.15-0.2 ms of a 2.4 ms iteration; on the
     // affine path the candidates are in the candidate arrays, where k_affine_commit wrote them)
-    if (spec) {
-      const size_t nn = (size_t)(P.N + 1) * P.Bp;
-      Timed t(h, st, 2);
-      hipLaunchKernelGGL(k_spec_commit, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, P);
-      LAUNCH_CHECK();
-    }
-    if ((rc = run_linearize<M>(h, Pw, st, P.cand, P.cand_u, P.cur, P.cur_u, 0, 0, -1, 0, P.affine ? 0 : NALPHA_SS - 1, spec))) return rc;
-    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it, spec ? 1 : 0);
+    if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 0, 0, -1, 0, P.affine ? 0 : NALPHA_SS - 1))) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
     LAUNCH_CHECK();
-    if (spec) { double* r = P.REC; P.REC = P.REC2; P.REC2 = r; }
   }
   return 0;
 }
@@ -4310,11 +4208,6 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
     if (P.m == 4) hipLaunchKernelGGL(k_init_rollout<4>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
     else hipLaunchKernelGGL(k_init_rollout<6>, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
     LAUNCH_CHECK();
-  }
-  if (opt->line_search || !ms) {
-    // the other record buffer of a search with a speculative first stage: K2 loads the records of a whole group of four, also
-    // of its inactive trajectories (whose lanes it ignores) -- those must be numbers, not what the workspace happened to hold
-    if (hipMemsetAsync(P.REC2, 0, sizeof(double) * (size_t)(P.N + 1) * P.recF * P.Bp, st) != hipSuccess) return TOLG_E_LAUNCH;
   }
   int rc = (P.m == 4) ? run_linearize<4>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms)
                       : run_linearize<6>(h, P, st, P.cur, P.cur_u, nullptr, nullptr, ms);
