@@ -578,6 +578,12 @@ def run_rank(args, rank, world):
             res = solver.solve_end()
     torch.cuda.synchronize(dev)
     active_end = float((res.iters == total).double().mean().item())
+    # iterations the trajectories of this rank actually ran inside the last timed region (a stopped trajectory runs none): the
+    # line-search lines report the rate over THAT work beside `value`, which counts every trajectory of the batch as iterated
+    if headline:
+        worked = None
+    else:
+        worked = float((res.iters.clamp(min=W, max=total) - W).double().sum().item())
     # final gather of costs / controls over RCCL (outside the timed solve, reported separately)
     gather_ms, gather_err = None, None
     if multi:
@@ -652,6 +658,12 @@ def run_rank(args, rank, world):
                                        % (B if args.scaling == "weak" else B_global),
                        "trajectory_iterations_per_s": value * (B if args.scaling == "weak" else B_global),
                        "active_fraction_at_region_end": active_end, "all_finite": finite, "all_status_ok": clean,
+                       **({"active_normalised": {
+                           "trajectory_iterations_run_in_last_region_rank0": worked,
+                           "share_of_batch_x_steps": worked / (B * K),
+                           "trajectory_iterations_per_s_rank0": worked / (regions[-1] if regions else float("nan")),
+                           "note": "value x batch counts a stopped trajectory as iterated; this is the last region's rate over the "
+                                   "iterations its trajectories really ran (rank 0's shard)"}} if worked is not None else {}),
                        **({"invalid": invalid} if invalid else {}),
                        "timed_regions": {"repeats": R, "steps_each": K,
                                          "reported": ("median of the regions WITHOUT per-kernel events (odd ones); kernel_ms_per_step "
