@@ -2569,7 +2569,10 @@ TOLG_DEV double ls_alpha_k(int k) { return pow(1.1, -(double)(k * k)); }
 // chain (k_rollout_eval_t) beyond: 64 waves per alpha whatever n is.  Measured at 4096 x 200, 12 alphas: quad form
 // 0.45 + 0.15 ms at n ~ 600, 1.36 + 0.39 ms at n ~ 2500; thread form 1.3-1.4 ms for any n.  Every kernel of a stage is
 // launched; the ones whose form is not in turn leave at once.
-enum { LS_QUAD_MAX = 20000 };
+// (round 4, with the rollouts in two waves per sixteen quads: 20000 -> 32000 measured +1.2 % on the SS line, 64000 -- the quad
+// form for every list of a 4096 batch -- the same; beyond ~36000 quads the quad form's 4.4 rounds of 0.3 ms pass the thread
+// form's one chain of 1.4 ms)
+enum { LS_QUAD_MAX = 32000 };
 TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots) { return list < 0 || P.ls_count[list] * nslots <= LS_QUAD_MAX; }
 
 // stage cost l(x, u, i) / terminal cost (traopt_cost.py:675-738)
