@@ -2837,36 +2837,49 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
 // step i needs twist i (twist wave's step i - 1): each is at most one step ahead of the other, so a slot written at step i
 // (knot i + 1) replaces knot i - 3, which both have long read.  Every poll is bounded (TOLG_ST_INTERNAL instead of a hang).
 // FACT: the merit search's step for alpha < 1; otherwise x^+ = f(x^, u^) (single shooting, and alpha = 1 of both searches).
+// NT twist waves share ONE pose wave (a pose lane per quad: the pose chain has no product to split over a quad's lanes): a workgroup
+// of NT = 3 twist waves + the pose wave carries 48 quads on the four SIMDs of a CU -- two waves per sixteen quads (NT = 1) put
+// a pose wave that mostly waits on every second SIMD, which a stage that fills the chip several times over (single shooting's
+// twelve step sizes) pays for in full.
 enum { L2_RING = 4 };
-template <int M, bool FACT>
-// (two waves per SIMD -- __launch_bounds__(128, 2): 256 registers, 220-340 bytes of scratch on the chain -- was measured: merit
-// 554 -> 414 it/s, SS 450 -> 308)
-__global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslots, int direct, int list) {
+// (two waves per SIMD -- __launch_bounds__(128, 2) on the NT = 1 form: 256 registers, 220-340 bytes of scratch on the chain -- was
+// measured: merit 554 -> 414 it/s, SS 450 -> 308)
+template <int M, bool FACT, int NT>
+__global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0, int nslots, int direct, int list) {
+  constexpr int NQ = 16 * NT;  // quads per workgroup
   const DConsts& C = *(const DConsts*)P.c;
-  __shared__ __attribute__((aligned(16))) double ring[L2_RING][7 * 32];  // rl_put_pose / rl_put_twist layout, pairs 0..6
-  __shared__ int sync[2];
+  __shared__ f64x2 ring[L2_RING][7][NQ];  // [slot][pair][quad]: pairs 0..3 the pose (quaternion, translation, padding), 4..6 the twist
+  __shared__ int sync[NT + 2];            // twists published by twist wave k (0 .. NT-1), poses published (NT), any live quad (NT + 1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 64 + lane, slot = blockIdx.y;
-  const int quad = t >> 2, q = t & 3, tt = lane >> 2;
+  const bool pose_wave = wave == NT;
+  const int slot = blockIdx.y;
+  // this lane's quad: a twist wave's lanes form sixteen quads of four, a pose-wave lane IS a quad (lanes past NQ idle along)
+  const int tq = pose_wave ? lane : wave * 16 + (lane >> 2);
+  const int tt = tq < NQ ? tq : NQ - 1;
+  const int quad = blockIdx.x * NQ + tt, q = pose_wave ? 0 : (lane & 3);
   if (slot >= nslots) return;
-  // (every return up to the barrier is taken by both waves or by neither: they map lanes to quads alike)
+  // (every return up to the barriers is taken by the whole workgroup)
   int b;
   bool live;
   if (list >= 0) {
     const int n = P.ls_count[list];
     if (n * nslots > LS_QUAD_MAX) return;  // the thread form's turn (ls_quad_form)
-    if ((quad & ~15) >= n) return;
-    live = quad < n;
-    b = P.ls_list[(size_t)list * P.Bp + (live ? quad : n - 1)];  // idle quads replay the last entry and store nothing
+    if ((int)blockIdx.x * NQ >= n) return;
+    live = quad < n && tq < NQ;
+    b = P.ls_list[(size_t)list * P.Bp + (quad < n ? quad : n - 1)];  // idle quads replay the last entry and store nothing
   } else {
-    live = quad < P.Bp;
-    b = live ? quad : P.Bp - 1;
-    live = live && P.active[b] && P.ls_accept[b] < 0;  // (decided or finished trajectories compute along and store nothing)
-    if (!__any(live)) return;
+    if ((int)blockIdx.x * NQ >= P.Bp) return;
+    b = quad < P.Bp ? quad : P.Bp - 1;
+    live = quad < P.Bp && tq < NQ && P.active[b] && P.ls_accept[b] < 0;  // (decided or finished trajectories compute along and store nothing)
   }
-  if (threadIdx.x < 2) sync[threadIdx.x] = 0;
+  if (threadIdx.x < NT + 2) sync[threadIdx.x] = 0;
   __syncthreads();
   const rl_sync_t vsy = (rl_sync_t)sync;
+  if (list < 0) {  // (kernel-uniform branch) a workgroup none of whose quads is undecided leaves
+    if (__any(live) && lane == 0) vsy[NT + 1] = 1;
+    __syncthreads();
+    if (vsy[NT + 1] == 0) return;
+  }
   const bool writer = live && q == 0;
   const int N = P.N, ai = a0 + slot;
   const double alpha = ls_alpha_k(ai), am1 = alpha - 1.0;
@@ -2876,8 +2889,8 @@ __global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslot
   double* sx = direct ? P.cand : P.slot_x + (size_t)slot * stStride * (N + 1);
   double* su = direct ? P.cand_u : P.slot_u + (size_t)slot * uStride * N;
   const DynK DK = dynk_load(*P.c);  // generic pointer: see the note at DConsts
-  if (wave == 0) {
-    // ---------------- the twist chain: xi^_{i+1} from x^_i (pose from the other wave), u^_i on the way
+  if (!pose_wave) {
+    // ---------------- a twist chain: xi^_{i+1} from x^_i (pose from the pose wave), u^_i on the way
     State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);  // x^_0 = x_0
     if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, Sn);
     double dA[FACT ? 6 : 1], dB[FACT ? 6 : 1];
@@ -2894,9 +2907,11 @@ __global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslot
       roll_load<M, !FACT>(P, i, b, q, vb, sB, R);  // in flight while the pose arrives and Log runs
       __builtin_amdgcn_sched_barrier(0);
       if (i > 0) {
-        if (!rl_wait_ge(vsy + 1, i)) { ok = false; return; }
+        if (!rl_wait_ge(vsy + NT, i)) { ok = false; return; }
         asm volatile("" ::: "memory");
-        Sn.X = rl_get_pose(ring[i % L2_RING], tt);
+        const f64x2 a = ring[i % L2_RING][0][tt], bq = ring[i % L2_RING][1][tt], c = ring[i % L2_RING][2][tt], d3 = ring[i % L2_RING][3][tt];
+        Sn.X.q.x = a.x; Sn.X.q.y = a.y; Sn.X.q.z = bq.x; Sn.X.q.w = bq.y;
+        Sn.X.t = v3(c.x, c.y, d3.x);
       }
       V3 ew, ev;
       const Pose Dx = se3_compose(se3_inverse(So.X), Sn.X);
@@ -2928,11 +2943,14 @@ __global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslot
         Sn.w = Fn.w;
         Sn.v = Fn.v;
       }
-      if (q == 0) rl_put_twist(ring[(i + 1) % L2_RING], tt, Sn.w, Sn.v);
+      if (q == 0) {
+        const int s1 = (i + 1) % L2_RING;
+        ring[s1][4][tt] = f64x2{Sn.w.x, Sn.w.y}; ring[s1][5][tt] = f64x2{Sn.w.z, Sn.v.x}; ring[s1][6][tt] = f64x2{Sn.v.y, Sn.v.z};
+      }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) vsy[0] = i + 1;
-      if (writer) {  // u^_i and the twist of x^_{i+1} (its pose is the other wave's to store)
+      if (lane == 0) vsy[wave] = i + 1;
+      if (writer) {  // u^_i and the twist of x^_{i+1} (its pose is the pose wave's to store)
         __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB), rSX = mkbuf(sx + stStride * (i + 1), 13 * sB);
 #pragma unroll
         for (int a = 0; a < M; a++) bst(rSU, vs, a * sB, un[a]);
@@ -2954,7 +2972,8 @@ __global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslot
     if (!ok && writer) P.status[b] = TOLG_ST_INTERNAL;
     return;
   }
-  // ---------------- the pose chain: X^_{i+1} = [M_i] project(X^_i Exp(xi^_i dt)), M_i = X_{i+1} Exp((alpha - 1) d_q) X_{i+1}^-1
+  // ---------------- the pose chains: X^_{i+1} = [M_i] project(X^_i Exp(xi^_i dt)), M_i = X_{i+1} Exp((alpha - 1) d_q) X_{i+1}^-1
+  const bool mine = tq < NQ;
   State S = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
   struct NomQ { Pose X; double d[6]; };
   auto load_nom = [&](int i, NomQ& n) {  // pose of the nominal x_{i+1} and the pose half of the stored defect d_i
@@ -2974,17 +2993,25 @@ __global__ __launch_bounds__(128) void k_rollout_ls2(Params P, int a0, int nslot
     if constexpr (FACT)
       Mx = se3_compose(se3_compose(n.X, se3_exp_fast(am1 * v3(n.d[0], n.d[1], n.d[2]), am1 * v3(n.d[3], n.d[4], n.d[5]))), se3_inverse(n.X));
     if (i > 0) {
-      if (!rl_wait_ge(vsy, i)) { ok = false; return; }
+#pragma unroll
+      for (int k = 0; k < NT; k++)
+        if (!rl_wait_ge(vsy + k, i)) { ok = false; return; }
       asm volatile("" ::: "memory");
-      rl_get_twist(ring[i % L2_RING], tt, S.w, S.v);
+      const f64x2 e = ring[i % L2_RING][4][tt], f = ring[i % L2_RING][5][tt], g = ring[i % L2_RING][6][tt];
+      S.w = v3(e.x, e.y, f.x);
+      S.v = v3(f.y, g.x, g.y);
     }
     Pose F = dyn_pose_k(DK, S);
     if constexpr (FACT) F = se3_project(se3_compose(Mx, F));
     S.X = F;
-    if (q == 0) rl_put_pose(ring[(i + 1) % L2_RING], tt, S.X);
+    if (mine) {
+      const int s1 = (i + 1) % L2_RING;
+      ring[s1][0][tt] = f64x2{S.X.q.x, S.X.q.y}; ring[s1][1][tt] = f64x2{S.X.q.z, S.X.q.w};
+      ring[s1][2][tt] = f64x2{S.X.t.x, S.X.t.y}; ring[s1][3][tt] = f64x2{S.X.t.z, 0.0};
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) vsy[1] = i + 1;
+    if (lane == 0) vsy[NT] = i + 1;
     if (writer) {
       __amdgpu_buffer_rsrc_t rSX = mkbuf(sx + stStride * (i + 1), 13 * sB);
       bst(rSX, vs, 0, S.X.q.x); bst(rSX, vs, sB, S.X.q.y); bst(rSX, vs, 2 * sB, S.X.q.z); bst(rSX, vs, 3 * sB, S.X.q.w);
@@ -4023,8 +4050,18 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
     {
       dim3 grid((P.Bp * 4 + 63) / 64, n), blk(64);  // four lanes per (trajectory, alpha)
       if (two) {
-        if (MS && !k3) hipLaunchKernelGGL((k_rollout_ls2<M, true>), grid, dim3(128), 0, st, P, a0, n, direct, list_in);
-        else hipLaunchKernelGGL((k_rollout_ls2<M, false>), grid, dim3(128), 0, st, P, a0, n, direct, list_in);
+        // twist waves per workgroup (k_rollout_ls2): the merit search's stages are a few hundred quads -- one chain's length, and
+        // a pose wave of its own per sixteen quads keeps that chain shortest (NT = 1; with NT = 3 merit 596 -> 526 it/s); single
+        // shooting's twelve step sizes fill the chip several times over and gain from fewer waves per quad (NT = 3: SS 517 -> 542)
+        if (MS) {
+          const dim3 g2((P.Bp + 15) / 16, n), b2(128);
+          if (!k3) hipLaunchKernelGGL((k_rollout_ls2<M, true, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
+          else hipLaunchKernelGGL((k_rollout_ls2<M, false, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
+        } else if (direct) {  // (its first try is one chain again: NT = 1, 542 -> 547)
+          hipLaunchKernelGGL((k_rollout_ls2<M, false, 1>), dim3((P.Bp + 15) / 16, n), dim3(128), 0, st, P, a0, n, direct, list_in);
+        } else {
+          hipLaunchKernelGGL((k_rollout_ls2<M, false, 3>), dim3((P.Bp + 47) / 48, n), dim3(256), 0, st, P, a0, n, direct, list_in);
+        }
       } else if (k3) {
       } else if (pend) {
         if (linear) hipLaunchKernelGGL((k_rollout_ls<6, MS, true, 1>), grid, blk, 0, st, P, a0, n, direct, list_in);
