@@ -2848,7 +2848,8 @@ template <int M, bool FACT, int NT>
 __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0, int nslots, int direct, int list) {
   constexpr int NQ = 16 * NT;  // quads per workgroup
   const DConsts& C = *(const DConsts*)P.c;
-  __shared__ f64x2 ring[L2_RING][7][NQ];  // [slot][pair][quad]: pairs 0..3 the pose (quaternion, translation, padding), 4..6 the twist
+  __shared__ f64x2 ring[L2_RING][10][NQ];  // [slot][pair][quad]: pairs 0..3 the pose (quaternion, translation, padding), 4..6 the twist,
+                                           // 7..9 the control that led to it (u^_{i-1} in the slot of knot i)
   __shared__ int sync[NT + 2];            // twists published by twist wave k (0 .. NT-1), poses published (NT), any live quad (NT + 1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool pose_wave = wave == NT;
@@ -2892,7 +2893,6 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
   if (!pose_wave) {
     // ---------------- a twist chain: xi^_{i+1} from x^_i (pose from the pose wave), u^_i on the way
     State Sn = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);  // x^_0 = x_0
-    if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, Sn);
     double dA[FACT ? 6 : 1], dB[FACT ? 6 : 1];
     auto load_d = [&](int i, double (&d)[FACT ? 6 : 1]) {  // the twist half of the stored defect
       if constexpr (FACT) {
@@ -2943,20 +2943,17 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
         Sn.w = Fn.w;
         Sn.v = Fn.v;
       }
+      // (no global store on this wave: the pose wave, which waits most of the time, stores the whole candidate -- a store in
+      // the memory queue makes every counted wait for a prefetched load a wait for the store as well)
       if (q == 0) {
         const int s1 = (i + 1) % L2_RING;
         ring[s1][4][tt] = f64x2{Sn.w.x, Sn.w.y}; ring[s1][5][tt] = f64x2{Sn.w.z, Sn.v.x}; ring[s1][6][tt] = f64x2{Sn.v.y, Sn.v.z};
+#pragma unroll
+        for (int a = 0; a < M; a += 2) ring[s1][7 + a / 2][tt] = f64x2{un[a], un[a + 1]};
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) vsy[wave] = i + 1;
-      if (writer) {  // u^_i and the twist of x^_{i+1} (its pose is the pose wave's to store)
-        __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * i, M * sB), rSX = mkbuf(sx + stStride * (i + 1), 13 * sB);
-#pragma unroll
-        for (int a = 0; a < M; a++) bst(rSU, vs, a * sB, un[a]);
-        bst(rSX, vs, 7 * sB, Sn.w.x); bst(rSX, vs, 8 * sB, Sn.w.y); bst(rSX, vs, 9 * sB, Sn.w.z);
-        bst(rSX, vs, 10 * sB, Sn.v.x); bst(rSX, vs, 11 * sB, Sn.v.y); bst(rSX, vs, 12 * sB, Sn.v.z);
-      }
     };
     State Sa = roll_load_state(P, 0, vb, sB), Sb = Sa;
     load_d(0, dA);
@@ -2975,6 +2972,20 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
   // ---------------- the pose chains: X^_{i+1} = [M_i] project(X^_i Exp(xi^_i dt)), M_i = X_{i+1} Exp((alpha - 1) d_q) X_{i+1}^-1
   const bool mine = tq < NQ;
   State S = load_state_b(mkbuf(P.cur, 13 * sB), vb, sB);
+  if (writer) store_state_b(mkbuf(sx, 13 * sB), vs, sB, S);
+  // twist of x^_i and the control u^_{i-1} that led to it, from slot i of the ring to the candidate's place
+  auto store_twist_u = [&](int i, V3 w, V3 v) {
+    if (writer) {
+      __amdgpu_buffer_rsrc_t rSU = mkbuf(su + uStride * (i - 1), M * sB), rSX = mkbuf(sx + stStride * i, 13 * sB);
+#pragma unroll
+      for (int a = 0; a < M; a += 2) {
+        const f64x2 u2 = ring[i % L2_RING][7 + a / 2][tt];
+        bst(rSU, vs, a * sB, u2.x); bst(rSU, vs, (a + 1) * sB, u2.y);
+      }
+      bst(rSX, vs, 7 * sB, w.x); bst(rSX, vs, 8 * sB, w.y); bst(rSX, vs, 9 * sB, w.z);
+      bst(rSX, vs, 10 * sB, v.x); bst(rSX, vs, 11 * sB, v.y); bst(rSX, vs, 12 * sB, v.z);
+    }
+  };
   struct NomQ { Pose X; double d[6]; };
   auto load_nom = [&](int i, NomQ& n) {  // pose of the nominal x_{i+1} and the pose half of the stored defect d_i
     if constexpr (FACT) {
@@ -3017,6 +3028,7 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
       bst(rSX, vs, 0, S.X.q.x); bst(rSX, vs, sB, S.X.q.y); bst(rSX, vs, 2 * sB, S.X.q.z); bst(rSX, vs, 3 * sB, S.X.q.w);
       bst(rSX, vs, 4 * sB, S.X.t.x); bst(rSX, vs, 5 * sB, S.X.t.y); bst(rSX, vs, 6 * sB, S.X.t.z);
     }
+    if (i > 0) store_twist_u(i, S.w, S.v);  // (behind the publish: off the chain)
   };
   for (int i = 0; ok && i < N; i += 2) {
     if (i + 1 < N) load_nom(i + 1, nB);
@@ -3026,6 +3038,14 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
     if (i + 2 < N) load_nom(i + 2, nA);
     __builtin_amdgcn_sched_barrier(0);
     pstep(i + 1, nB);
+  }
+  if (ok) {  // the last twist and control
+#pragma unroll
+    for (int k = 0; k < NT; k++)
+      if (!rl_wait_ge(vsy + k, N)) return;  // (the twist wave reports it)
+    asm volatile("" ::: "memory");
+    const f64x2 e = ring[N % L2_RING][4][tt], f = ring[N % L2_RING][5][tt], g = ring[N % L2_RING][6][tt];
+    store_twist_u(N, v3(e.x, e.y, f.x), v3(f.y, g.x, g.y));
   }
 }
 // stage cost l(x^_i, u^_i) (traopt_cost.py:675-738) and, MS, the squared defect
