@@ -21,7 +21,21 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def _dense(prob):
+    """The same problem with full inertia blocks (a rotated body frame's inertia): the backward sweep and the ring kernel then read
+    I + H dt from the record (Params::fA22 >= 0) instead of rebuilding it from the twist."""
+    A = np.array([[0.10, -0.05, 0.02], [0.03, 0.12, -0.04], [-0.02, 0.06, 0.09]])
+    Jd = np.array(prob.J, dtype=float).copy()
+    Jd[:3, :3] += A @ A.T
+    if prob.kind == "se3":
+        Jd[3:, 3:] += 0.5 * (A @ A.T)
+    return TrackingProblem(prob.kind, Jd, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
+
+
 def _problem(kind, B, N):
+    if kind.endswith("_dense"):
+        prob, x0_q, x0_xi, us0 = _problem(kind[:-6], B, N)
+        return _dense(prob), x0_q, x0_xi, us0
     if kind == "se3":
         return workloads.se3_tracking(B, N=N, R_scale=1e-3)
     if kind == "drone":
@@ -44,7 +58,8 @@ def _random_traj(prob, B, seed, spread):
 
 
 @pytest.mark.parametrize("kind,B,N", [("se3", 7, 33), ("se3", 64, 200), ("drone", 5, 60), ("drone", 12, 150), ("so3", 4, 40),
-                                      ("se3", 1, 1), ("se3", 3, 2), ("drone", 2, 3), ("se3", 5, 5), ("se3", 17, 6)])  # horizons shorter than the ring
+                                      ("se3", 1, 1), ("se3", 3, 2), ("drone", 2, 3), ("se3", 5, 5), ("se3", 17, 6),  # horizons shorter than the ring
+                                      ("se3_dense", 7, 33), ("se3_dense", 21, 120), ("drone_dense", 6, 50), ("se3_dense", 3, 2)])
 @pytest.mark.parametrize("spread", [0.02, 0.15])
 def test_ring_kernel_matches_statement_kernel_on_random_trajectories(kind, B, N, spread):
     """The two kernels on the same records and gains (open trajectories with defects of size `spread`): first- and
@@ -106,7 +121,7 @@ def _same_search(it_a, J_a, A_a, it_b, J_b, A_b, tol, what):
     return same
 
 
-@pytest.mark.parametrize("kind,B,N", [("se3", 6, 50), ("se3", 9, 37), ("drone", 5, 60), ("so3", 4, 40)])
+@pytest.mark.parametrize("kind,B,N", [("se3", 6, 50), ("se3", 9, 37), ("drone", 5, 60), ("so3", 4, 40), ("se3_dense", 7, 45), ("drone_dense", 5, 40)])
 def test_ring_form_matches_statement_form_and_oracle(kind, B, N):
     """Same accepted step sizes, same costs (the two kernels differ by Exp/Log round trips and the order of two sums);
     B not a multiple of 4 exercises the padded group, N not a multiple of 4 the ring's tail steps."""

@@ -19,10 +19,15 @@
 // A trajectory whose rotation deviation reaches 3 rad at some knot (or is not finite) is flagged instead of written;
 // k_expected_change, launched behind this kernel with REDO, recomputes exactly those with the reference's group
 // operations.  Results agree with that kernel to rounding (Exp / Log round trips removed, sums
-// taken per lane over the horizon, then across the lanes).  Models: diagonal inertia blocks and a constant input
-// matrix (Params::fA22 < 0: every reference script except the pendulum); the others keep k_expected_change.
-enum { EC_DEPTH = 4, EC_RECB = 4096, EC_GKB = 3072, EC_ZP = EC_RECB + EC_GKB, EC_SLOT = EC_ZP + 64,
-       EC_SCR = EC_DEPTH * EC_SLOT, EC_LDS = EC_SCR + 4 * 16 * 2 * 8 };
+// taken per lane over the horizon, then across the lanes).  Models: a constant input matrix -- every reference script except the
+// pendulum, which keeps k_expected_change.  DENSE (round 4): inertia blocks that are not diagonal -- the velocity block I + H dt
+// is then a field of the record (Params::fA22 >= 0, 36 more doubles: the record run of four trajectories passes 4 KB and takes a
+// fifth LDS-DMA chunk) and its rows are read from the ring like the pose rows instead of being rebuilt from the twist.
+enum { EC_DEPTH = 4, EC_GKB = 3072 };
+template <bool DENSE>
+struct EcLds {  // one ring slot: the record run (4 or 5 KB), the gain run, a zero pad; behind the ring the scratch of the final sums
+  enum { RECB = DENSE ? 5120 : 4096, ZP = RECB + EC_GKB, SLOT = ZP + 64, SCR = EC_DEPTH * SLOT, LDS = SCR + 4 * 16 * 2 * 8 };
+};
 
 // n KB of one contiguous block by LDS-DMA, 16 bytes per lane and instruction; v[k] is the lane's byte offset for
 // chunk k, clamped by the caller so that no lane reads past the block (lanes past its end re-read its last 16 bytes).
@@ -41,6 +46,13 @@ TOLG_DEV void ec_dma3(const void* sbase, unsigned v0, unsigned v1, unsigned v2, 
                "global_load_lds_dwordx4 %3, %4 offset:2048" TOLG_POL(TOLG_NT_EC) "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(sbase), "s"(lds_dst) : "memory");
+}
+TOLG_DEV void ec_dma1(const void* sbase, unsigned v0, unsigned lds_dst) {  // (the instruction offset ends at 4095: a fifth KB is
+  unsigned keep;                                                           // a request of its own, with its own LDS base)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\t"
+               "global_load_lds_dwordx4 %1, %2" TOLG_POL(TOLG_NT_EC) "\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "s"(sbase), "s"(lds_dst) : "memory");
 }
 TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3_, unsigned lds_dst) {
   unsigned keep;
@@ -61,8 +73,11 @@ TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, 
 // The stores are two global_store_dwordx2 per step, issued by every lane of every wave that runs the loop (lanes without a
 // row write zeros into the padding), in asm so that they take a KNOWN place in the in-order memory queue: the counted waits
 // on the DMA ring add them up.
-template <int M, bool GRAV, bool STORE = false>
+template <int M, bool GRAV, bool STORE = false, bool DENSE = false>
 __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
+  static_assert(!(STORE && DENSE), "the affine linear-rollout path is built for the models of the third backward form");
+  typedef EcLds<DENSE> L;
+  constexpr unsigned EC_RECB = L::RECB, EC_ZP = L::ZP, EC_SLOT = L::SLOT, EC_SCR = L::SCR, EC_LDS = L::LDS;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.x * 4 + g;  // Bp is a multiple of 4
   const bool act = P.active[b] != 0;
@@ -103,6 +118,12 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   const bool vrow = j >= 6 && j < 12;
   const int rr = vrow ? (j - 6) % 3 : 0, pI = (rr + 1) % 3, nI = (rr + 2) % 3;
   const unsigned oXp = lg + FOFF(REC_XI + 2 * pI), oXn = lg + FOFF(REC_XI + 2 * nI);  // (w_k, v_k) pairs
+  // DENSE: row j - 6 of the stored I + H dt (column-major block, a22_build) instead
+  unsigned oA[DENSE ? 6 : 1];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) oA[c] = vrow ? lg + FOFF((unsigned)P.fA22 + 6u * c + (unsigned)(j - 6)) : ZP;
+  }
   double cf[8];  // (alpha, beta) of a_n, a_p, c_n, c_p
   double mN[3], mP[3];
 #pragma unroll
@@ -150,9 +171,9 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   const int nkbR = (int)((recBytes + 1023u) / 1024u);
   constexpr int nkbG = (int)((gkBytes + 1023u) / 1024u);
   static_assert(nkbG == 2 || nkbG == 3, "gain block of four trajectories: 2 or 3 KB");
-  unsigned vR[4], vG[3];
+  unsigned vR[5], vG[3];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 5; k++) {
     const unsigned want = (unsigned)lane * 16u + 1024u * k, last = recBytes - 16u;
     vR[k] = ((want < last) ? want : last) - 1024u * k;  // chunks past the block are never issued (nkbR)
   }
@@ -168,12 +189,16 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)s * EC_SLOT));
     const void* rs = uniform_ptr(recBase + recStrideB * (size_t)i);
     const void* gs = uniform_ptr(gkBase + gStrideB * (size_t)i);
-    if (nkbR == 4) ec_dma4(rs, vR[0], vR[1], vR[2], vR[3], dst);
+    if constexpr (DENSE) {  // 130..136 fields: 4160..4352 bytes
+      ec_dma4(rs, vR[0], vR[1], vR[2], vR[3], dst);
+      ec_dma1(rs, vR[4] + 4096u, dst + 4096u);
+    }
+    else if (nkbR == 4) ec_dma4(rs, vR[0], vR[1], vR[2], vR[3], dst);
     else ec_dma3(rs, vR[0], vR[1], vR[2], dst);
     if constexpr (nkbG == 3) ec_dma3(gs, vG[0], vG[1], vG[2], dst + EC_RECB);
     else ec_dma2(gs, vG[0], vG[1], dst + EC_RECB);
   };
-  const int ndma = nkbR + nkbG;  // 5..7 instructions per knot
+  const int ndma = nkbR + nkbG;  // 5..8 instructions per knot
 
   // every constant is in its register before the sweep starts: the compiler's bookkeeping of its own loads (the
   // constants come through the generic pointer) must never meet the DMA queue inside the knot loop, where a
@@ -219,14 +244,16 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     constexpr int NST = STORE ? 2 * (EC_DEPTH - 1) : 0;
     if (STORE && i < EC_DEPTH - 1) {
       if (i + EC_DEPTH - 2 <= N - 1) {
-        if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7) : "memory");
+        if (ndma == 8) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 8) : "memory");
+        else if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7) : "memory");
         else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else if (i + EC_DEPTH - 2 <= N - 1) {
-      if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7 + NST) : "memory");
+      if (ndma == 8) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 8 + NST) : "memory");
+      else if (ndma == 7) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 7 + NST) : "memory");
       else if (ndma == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 6 + NST) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((EC_DEPTH - 2) * 5 + NST) : "memory");
     } else {
@@ -244,6 +271,11 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     for (int c = 0; c < 6; c++) Lr[c] = ld(oLXX[c]);
     const double d = ld(oD), lx = ld(oLX), lu = ld(oLU), luu = ld(oLUU);
     const f64x2 Xp = *reinterpret_cast<const f64x2*>(sl + oXp), Xn = *reinterpret_cast<const f64x2*>(sl + oXn);
+    double Ar[DENSE ? 6 : 1];
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) Ar[c] = ld(oA[c]);
+    }
     if constexpr (GRAV) {
       const double g0 = ld(oRTE), g1 = ld(oRTE + (FOFF(REC_LU + M + 1) - FOFF(REC_LU + M))),
                    g2 = ld(oRTE + (FOFF(REC_LU + M + 2) - FOFF(REC_LU + M)));
@@ -273,12 +305,15 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
       a2 = fma(du, t, a2);
     }
     // e' = F_x e + F_u du + d   (:2730-2737 with Log(Exp(v)) = v)
-    double y = mV * e;
+    double y = DENSE ? 0.0 : mV * e;
     y = fma(bcast<0>(e), F[0], y); y = fma(bcast<1>(e), F[1], y); y = fma(bcast<2>(e), F[2], y);
     y = fma(bcast<3>(e), F[3], y); y = fma(bcast<4>(e), F[4], y); y = fma(bcast<5>(e), F[5], y);
     y = fma(bcast<6>(e), F[6], y); y = fma(bcast<7>(e), F[7], y); y = fma(bcast<8>(e), F[8], y);
     y = fma(bcast<9>(e), F[9], y); y = fma(bcast<10>(e), F[10], y); y = fma(bcast<11>(e), F[11], y);
-    {
+    if constexpr (DENSE) {
+      y = fma(bcast<6>(e), Ar[0], y); y = fma(bcast<7>(e), Ar[1], y); y = fma(bcast<8>(e), Ar[2], y);
+      y = fma(bcast<9>(e), Ar[3], y); y = fma(bcast<10>(e), Ar[4], y); y = fma(bcast<11>(e), Ar[5], y);
+    } else {
       const double cAn = fma(cf[0], Xp.x, cf[1] * Xp.y), cAp = fma(cf[2], Xn.x, cf[3] * Xn.y);
       const double cCn = fma(cf[4], Xp.x, cf[5] * Xp.y), cCp = fma(cf[6], Xn.x, cf[7] * Xn.y);
       const double sAn = fma(bcast<8>(e), mN[2], fma(bcast<7>(e), mN[1], bcast<6>(e) * mN[0]));

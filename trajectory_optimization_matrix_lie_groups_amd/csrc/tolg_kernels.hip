@@ -4022,6 +4022,19 @@ static int run_rollout_ms(tolg_handle_s* h, const Params& P, hipStream_t st, dou
   LAUNCH_CHECK();
   return 0;
 }
+// the merit search's preparation in its ring form (tolg_expected_change.h): gravity / dense-inertia instantiations
+template <int M>
+static void launch_ec_ring(const tolg_handle_s* h, const Params& P, hipStream_t st) {
+  const dim3 gr(P.Bp / 4), blk(64);
+  const bool grav = h->hc.grav != 0.0, dense = P.fA22 >= 0;
+  if (dense) {
+    if (grav) hipLaunchKernelGGL((k_expected_change_ring<M, true, false, true>), gr, blk, 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change_ring<M, false, false, true>), gr, blk, 0, st, P);
+  } else {
+    if (grav) hipLaunchKernelGGL((k_expected_change_ring<M, true>), gr, blk, 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change_ring<M, false>), gr, blk, 0, st, P);
+  }
+}
 // rollout = 'linear', models of the third backward form: the alpha = 1 linear rollout as an affine recursion, e_i and du_i
 // left in P.ED (tolg_expected_change.h, STORE), plus -- what the kernel is named after -- the expected cost change and the
 // defect weight of the merit search.  The trajectories it hands back get their expected change from the statement form.
@@ -4186,11 +4199,10 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if (hipEventRecord(h->side_ev[0], st) != hipSuccess || hipStreamWaitEvent(h->side, h->side_ev[0], 0) != hipSuccess) return TOLG_E_LAUNCH;
       if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
         hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
-      else if (P.fA22 < 0 && opt->schedule != TOLG_SCHED_SPLIT) {
+      else if (opt->schedule != TOLG_SCHED_SPLIT) {
         // the affine recursion in the backward sweep's lane map, inputs through an LDS ring (tolg_expected_change.h);
         // behind it the statement-by-statement form for the trajectories it hands back (rotation deviations near pi)
-        if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true>), dim3(P.Bp / 4), dim3(64), 0, h->side, P);
-        else hipLaunchKernelGGL((k_expected_change_ring<M, false>), dim3(P.Bp / 4), dim3(64), 0, h->side, P);
+        launch_ec_ring<M>(h, P, h->side);
         LAUNCH_CHECK();
         hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       } else
@@ -4490,7 +4502,7 @@ extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, do
   if (!h || h->running || B < 1 || B > h->max_batch || form < 0 || form > 2) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
-  const bool ring_ok = P.fA22 < 0 && h->prob.kind != TOLG_DYN_PENDULUM3D;
+  const bool ring_ok = h->prob.kind != TOLG_DYN_PENDULUM3D;
   if (form != 0 && !ring_ok) return TOLG_E_ARG;
   hipLaunchKernelGGL(k_clear_ecc, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
   LAUNCH_CHECK();
@@ -4502,14 +4514,8 @@ extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, do
     else if (h->prob.kind == TOLG_DYN_PENDULUM3D) hipLaunchKernelGGL((k_expected_change<6, 1>), gq, blk, 0, st, P);
     else hipLaunchKernelGGL((k_expected_change<6, 0>), gq, blk, 0, st, P);
   } else {
-    const bool grav = h->hc.grav != 0.0;
-    if (P.m == 4) {
-      if (grav) hipLaunchKernelGGL((k_expected_change_ring<4, true>), gr, blk, 0, st, P);
-      else hipLaunchKernelGGL((k_expected_change_ring<4, false>), gr, blk, 0, st, P);
-    } else {
-      if (grav) hipLaunchKernelGGL((k_expected_change_ring<6, true>), gr, blk, 0, st, P);
-      else hipLaunchKernelGGL((k_expected_change_ring<6, false>), gr, blk, 0, st, P);
-    }
+    if (P.m == 4) launch_ec_ring<4>(h, P, st);
+    else launch_ec_ring<6>(h, P, st);
     LAUNCH_CHECK();
     if (form == 2) {
       if (P.m == 4) hipLaunchKernelGGL((k_expected_change<4, 0, true>), gq, blk, 0, st, P);
