@@ -158,7 +158,7 @@ struct Params {
   const double* al_lambda;  // [B][N][2m]
   const double* al_imu;     // [B][N][2m] diagonal of I_mu
 };
-enum { NSLOT = 12, NALPHA_MS = 20, NALPHA_SS = 13 };  // slots: the widest stage (the first alpha goes straight to the candidate arrays)
+enum { NSLOT = 15, NALPHA_MS = 20, NALPHA_SS = 13 };  // slots: the widest stage (the merit search's last: step sizes 5 .. 19; the first alpha goes straight to the candidate arrays)
 
 // every array is knot-major [knot][field][Bp]: one knot of one field is a contiguous run over the batch
 #define SIDX(c, i, b) ((((size_t)(i)) * 13 + (size_t)(c)) * (size_t)P.Bp + (size_t)(b))
@@ -4074,7 +4074,8 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   }
   {
     Timed t(h, st, 1);
-    if (!direct) {  // the thread form of a wide stage: runs when the list is long (ls_quad_form), leaves at once otherwise
+    if (!direct && (size_t)P.Bp * n > (size_t)LS_QUAD_MAX) {  // the thread form of a wide stage: runs when the list is long
+                                                               // (ls_quad_form), leaves at once otherwise; not launched where no list of this batch can be that long
       dim3 grid((P.Bp + 63) / 64, n), blk(64);
       if (linear) hipLaunchKernelGGL((k_rollout_eval_t<M, MS, true>), grid, blk, 0, st, P, a0, n, list_in);
       else hipLaunchKernelGGL((k_rollout_eval_t<M, MS, false>), grid, blk, 0, st, P, a0, n, list_in);
@@ -4174,6 +4175,8 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       if ((rc = run_affine_dev<M>(h, P, st, true))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 0, 0, 1, 1))) return rc;
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, 1))) return rc;
+      // (8 + 7 here: on the affine path the deep stages are not empty -- a sixth of the benchmark's trajectories search to the
+      // end -- and one stage of 15 was measured slower, 531 -> 487 it/s)
       if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, 1))) return rc;
       if (!so3_family(h->prob.kind))
         if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, 1))) return rc;
@@ -4222,13 +4225,13 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
       // (the last stage leaves what it accepted in its slots: the re-linearisation reads it there)
       const bool so3f = so3_family(h->prob.kind);
       if ((rc = run_ls_stage<M, true>(h, P, st, 1, 1, 4, opt->rollout_linear))) return rc;
-      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, 8, opt->rollout_linear, nullptr, so3f))) return rc;
-      if (!so3f)
-        if ((rc = run_ls_stage<M, true>(h, P, st, 3, 13, 7, opt->rollout_linear, nullptr, true))) return rc;
+      // (round 4, end: the step sizes 5 .. 19 in ONE last stage instead of 8 + 7 -- both are nearly empty on every workload seen,
+      // and an empty stage is still seven small launches, 0.05 ms of a 1.6 ms iteration)
+      if ((rc = run_ls_stage<M, true>(h, P, st, 2, 5, so3f ? 8 : 15, opt->rollout_linear, nullptr, true))) return rc;
       hipLaunchKernelGGL(k_ls_finish, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P, it);
       LAUNCH_CHECK();
-      ls_list_last = so3f ? 1 : 0;   // the list the last stage ran on: (stage - 1) & 1
-      ls_n_last = so3f ? 8 : 7;
+      ls_list_last = 1;   // the list the last stage ran on: (stage - 1) & 1
+      ls_n_last = so3f ? 8 : 15;
     }
     // the accepted candidate becomes the nominal trajectory while it is re-linearised
     if ((rc = run_linearize<M>(h, P, st, P.cand, P.cand_u, P.cur, P.cur_u, 1, 0, -1, ls_list_last, ls_n_last))) return rc;
