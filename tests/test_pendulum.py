@@ -153,6 +153,68 @@ def test_gpu_pendulum_knot_quantities_match_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spread", [0.03, 0.4])
+def test_gpu_pendulum_expected_change_ring_matches_statement_form(spread):
+    """The merit search's preparation for this model in its ring form (k_expected_change_ring<.., DENSE, VARB>: the velocity block
+    and the knot's input matrix read from the record run) against the kernel that walks the reference's statements
+    (traopt_controller.py:2730-2737, :2756-2769 over Pendulum3dDyanmics.f_x / f_u, traopt_dynamics.py:566-609), on open trajectories
+    with defects of size `spread`; what the ring form hands back the statement form fills in."""
+    import torch
+    from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR
+    B = 9
+    prob, *_ = workloads.pendulum_swingup(B)
+    N = prob.N
+    rng = np.random.default_rng(11)
+    xs_q = np.tile(np.eye(4), (B, N + 1, 1, 1)); xs_xi = np.zeros((B, N + 1, 6)); us = np.zeros((B, N, 6))
+    for b in range(B):
+        for i in range(N + 1):
+            xs_q[b, i, :3, :3] = prob.q_ref[i, :3, :3] @ Rot.from_rotvec(rng.normal(size=3) * spread).as_matrix()
+            xs_xi[b, i, :3] = prob.xi_ref[i, :3] + rng.normal(size=3) * spread
+        us[b, :, :3] = rng.normal(size=(N, 3))
+    solver = BatchedTrackingILQR(prob, B)
+    solver.linearize_backward(xs_q, xs_xi, us, ms=True)
+    es, _ = solver.expected_change(B, "statement")
+    er, flag = solver.expected_change(B, "ring")
+    er2, flag2 = solver.expected_change(B, "ring")
+    ea, _ = solver.expected_change(B, "auto")
+    torch.cuda.synchronize()
+    es, er, er2, ea, flag, flag2 = (t.cpu().numpy() for t in (es, er, er2, ea, flag, flag2))
+    np.testing.assert_array_equal(flag, flag2)
+    np.testing.assert_array_equal(er, er2)
+    keep = flag == 0
+    assert keep.sum() >= (B // 2 if spread < 0.1 else 1)
+    assert np.isfinite(es).all()
+    scale = np.abs(es).max(axis=1, keepdims=True)
+    assert (np.abs(er[keep] - es[keep]) / scale[keep]).max() < 1e-11
+    assert np.isnan(er[~keep]).all()
+    np.testing.assert_array_equal(ea[~keep], es[~keep])
+    np.testing.assert_array_equal(ea[keep], er[keep])
+
+
+@pytest.mark.gpu
+def test_gpu_pendulum_merit_search_ring_and_statement_schedules_agree():
+    """A merit-search solve with the ring form (schedule auto) and with the statement form alone (split): same step sizes, costs
+    to rounding, and the oracle's."""
+    from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR
+    B, K = 7, 10
+    prob, x0_q, x0_xi, us0 = workloads.pendulum_swingup(B, xi0_scale=1.0)
+    res = {}
+    for sched in ("auto", "split"):
+        r = BatchedTrackingILQR(prob, B).fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=K, tol_grad_norm=0.0, tol_d_norm=0.0,
+                                                   line_search=True, rollout="nonlinear", schedule=sched)
+        res[sched] = (r.J_hist.cpu().numpy(), r.alpha_hist.cpu().numpy(), r.iters.cpu().numpy())
+    (Ja, Aa, ia), (Js, As, is_) = res["auto"], res["split"]
+    np.testing.assert_array_equal(ia, is_)
+    o = ob.fit_batch(_oracle_of(prob), x0_q, x0_xi, us0, mode="ms", max_iter=K, line_search=True, rollout="nonlinear")
+    for b in range(B):
+        n = ia[b]
+        assert _rel(Ja[b, :n], Js[b, :n]) < 1e-10
+        np.testing.assert_allclose(Aa[b, : n - 1], As[b, : n - 1], rtol=1e-14)
+        m = min(n, o["iters"][b])
+        assert _rel(Ja[b, :m], o["J_hist"][b, :m]) < 1e-8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,line_search,rollout", [("ms", True, "nonlinear"), ("ms", False, "nonlinear"),
                                                       ("ss", False, "nonlinear"), ("ms", False, "linear")])
 def test_gpu_pendulum_fit_matches_oracle(mode, line_search, rollout):

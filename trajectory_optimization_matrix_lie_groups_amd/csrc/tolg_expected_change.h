@@ -73,9 +73,12 @@ TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, 
 // The stores are two global_store_dwordx2 per step, issued by every lane of every wave that runs the loop (lanes without a
 // row write zeros into the padding), in asm so that they take a KNOWN place in the in-order memory queue: the counted waits
 // on the DMA ring add them up.
-template <int M, bool GRAV, bool STORE = false, bool DENSE = false>
+// VARB (with DENSE and GRAV: Pendulum3dDyanmics): the input matrix differs from knot to knot -- its 3 x 3 block F_u[6:9, 0:3] is the
+// record's REC_BU (which takes REC_TRI's place; the block it displaces is zero for this model) and is read from the ring.
+template <int M, bool GRAV, bool STORE = false, bool DENSE = false, bool VARB = false>
 __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
   static_assert(!(STORE && DENSE), "the affine linear-rollout path is built for the models of the third backward form");
+  static_assert(!VARB || (DENSE && GRAV && M == 6), "VARB: the pendulum's instantiation");
   typedef EcLds<DENSE> L;
   constexpr unsigned EC_RECB = L::RECB, EC_ZP = L::ZP, EC_SLOT = L::SLOT, EC_SCR = L::SCR, EC_LDS = L::LDS;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
     int f = -1;
     const int cb = c / 3, cc = c % 3;
     if (j < 3) f = (cb == 0) ? REC_RI : (cb == 2) ? REC_JR : -1;
-    else if (j < 6) f = (cb == 0) ? REC_TRI : (cb == 1) ? REC_RI : (cb == 2) ? REC_QR : REC_JR;
+    else if (j < 6) f = (cb == 0) ? (VARB ? -1 : REC_TRI) : (cb == 1) ? REC_RI : (cb == 2) ? REC_QR : REC_JR;
     oF[c] = (f >= 0) ? lg + FOFF(f + 3 * cc + r3) : ZP;
   }
   const unsigned oD = (j < 12) ? lg + FOFF(REC_D + j) : ZP;
@@ -145,10 +148,16 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
       cf[4] = -sT * jvn; cf[5] = sT * ms - sB * jvn; cf[6] = sT * jvp; cf[7] = sB * jvp - sT * ms;
     }
   }
+  // VARB: rows 6..8 take their first three entries from the record (row-major 3 x 3 at REC_BU)
+  unsigned oBU[VARB ? 3 : 1];
+  if constexpr (VARB) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) oBU[k] = (vrow && j < 9) ? lg + FOFF(REC_BU + 3 * (j - 6) + k) : ZP;
+  }
   double fuc[M], R2r[M], W2r[6], P2r[6];
 #pragma unroll
   for (int k = 0; k < M; k++) {
-    fuc[k] = mV * fu_entry<M>(G, j6, k);               // F_u[j][k]
+    fuc[k] = (VARB && vrow && j < 9 && k < 3) ? 0.0 : mV * fu_entry<M>(G, j6, k);  // F_u[j][k]
     R2r[k] = mU * 2.0 * G.R[(j < M ? j : 0) * M + k];  // l_uu row
   }
 #pragma unroll
@@ -322,8 +331,14 @@ __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
       const double sCp = fma(bcast<11>(e), mP[2], fma(bcast<10>(e), mP[1], bcast<9>(e) * mP[0]));
       y = fma(cAn, sAn, y); y = fma(cAp, sAp, y); y = fma(cCn, sCn, y); y = fma(cCp, sCp, y);
     }
-    y = fma(bcast<0>(du), fuc[0], y); y = fma(bcast<1>(du), fuc[1], y);
-    y = fma(bcast<2>(du), fuc[2], y); y = fma(bcast<3>(du), fuc[3], y);
+    if constexpr (VARB) {
+      y = fma(bcast<0>(du), ld(oBU[0]) + fuc[0], y); y = fma(bcast<1>(du), ld(oBU[1]) + fuc[1], y);
+      y = fma(bcast<2>(du), ld(oBU[2]) + fuc[2], y);
+    } else {
+      y = fma(bcast<0>(du), fuc[0], y); y = fma(bcast<1>(du), fuc[1], y);
+      y = fma(bcast<2>(du), fuc[2], y);
+    }
+    y = fma(bcast<3>(du), fuc[3], y);
     if constexpr (M == 6) { y = fma(bcast<4>(du), fuc[4], y); y = fma(bcast<5>(du), fuc[5], y); }
     y += d;
     {  // Log(Exp(v)) = v needs a rotation part below pi: |v_rot| < 3 stays here, anything else is handed back

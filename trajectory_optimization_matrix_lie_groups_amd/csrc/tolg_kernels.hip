@@ -4027,7 +4027,9 @@ template <int M>
 static void launch_ec_ring(const tolg_handle_s* h, const Params& P, hipStream_t st) {
   const dim3 gr(P.Bp / 4), blk(64);
   const bool grav = h->hc.grav != 0.0, dense = P.fA22 >= 0;
-  if (dense) {
+  if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D) {
+    hipLaunchKernelGGL((k_expected_change_ring<6, true, false, true, true>), gr, blk, 0, st, P);
+  } else if (dense) {
     if (grav) hipLaunchKernelGGL((k_expected_change_ring<M, true, false, true>), gr, blk, 0, st, P);
     else hipLaunchKernelGGL((k_expected_change_ring<M, false, false, true>), gr, blk, 0, st, P);
   } else {
@@ -4200,14 +4202,17 @@ static int iterate_ms(tolg_handle_s* h, const Params& P, const tolg_options* opt
         h->side_ev[0] = ev[0]; h->side_ev[1] = ev[1]; h->side = sd;
       }
       if (hipEventRecord(h->side_ev[0], st) != hipSuccess || hipStreamWaitEvent(h->side, h->side_ev[0], 0) != hipSuccess) return TOLG_E_LAUNCH;
-      if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
+      if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D && opt->schedule == TOLG_SCHED_SPLIT)
         hipLaunchKernelGGL((k_expected_change<6, 1>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       else if (opt->schedule != TOLG_SCHED_SPLIT) {
         // the affine recursion in the backward sweep's lane map, inputs through an LDS ring (tolg_expected_change.h);
         // behind it the statement-by-statement form for the trajectories it hands back (rotation deviations near pi)
         launch_ec_ring<M>(h, P, h->side);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
+        if (M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D)
+          hipLaunchKernelGGL((k_expected_change<6, 1, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
+        else
+          hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       } else
         hipLaunchKernelGGL((k_expected_change<M, 0>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, h->side, P);
       LAUNCH_CHECK();
@@ -4505,8 +4510,7 @@ extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, do
   if (!h || h->running || B < 1 || B > h->max_batch || form < 0 || form > 2) return TOLG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Params P = params_for(h, B);
-  const bool ring_ok = h->prob.kind != TOLG_DYN_PENDULUM3D;
-  if (form != 0 && !ring_ok) return TOLG_E_ARG;
+  const bool pend = h->prob.kind == TOLG_DYN_PENDULUM3D;
   hipLaunchKernelGGL(k_clear_ecc, dim3((P.Bp + 63) / 64), dim3(64), 0, st, P);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_poison_lds, dim3(2048), dim3(256), 0, st);
@@ -4522,6 +4526,7 @@ extern "C" int tolg_expected_change(tolg_handle_t h, int32_t form, int32_t B, do
     LAUNCH_CHECK();
     if (form == 2) {
       if (P.m == 4) hipLaunchKernelGGL((k_expected_change<4, 0, true>), gq, blk, 0, st, P);
+      else if (pend) hipLaunchKernelGGL((k_expected_change<6, 1, true>), gq, blk, 0, st, P);
       else hipLaunchKernelGGL((k_expected_change<6, 0, true>), gq, blk, 0, st, P);
     }
   }
