@@ -129,3 +129,14 @@ def test_dense_inertia():
     o = _oracle(pd, x0_q, x0_xi, us0, K, "ms")
     n = int(min(o["iters"].min(), ra.iters.min().item()))
     assert _rel(ra.J_hist.cpu().numpy()[:, :n], o["J_hist"][:, :n]) < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["ms", "ss"])
+def test_pendulum_stages_in_two_waves(mode):
+    """Pendulum3dDyanmics (k_rollout_ls2<6, ., 1, PK = 1>: the twist chain reads the pose it was handed for the gravity torque):
+    two-wave against one-wave stage kernels (the oracle comparison of these solves is tests/test_pendulum.py's)."""
+    B, K = 11, 10
+    prob, x0_q, x0_xi, us0 = workloads.pendulum_swingup(B, xi0_scale=1.0)
+    ra = _fit(prob, x0_q, x0_xi, us0, K, False, mode=mode, line_search=True)
+    rb = _fit(prob, x0_q, x0_xi, us0, K, True, mode=mode, line_search=True)
+    _same(ra, rb)

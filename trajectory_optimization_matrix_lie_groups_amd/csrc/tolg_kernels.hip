@@ -2844,7 +2844,7 @@ __global__ __launch_bounds__(64) void k_rollout_ls(Params P, int a0, int nslots,
 enum { L2_RING = 4 };
 // (two waves per SIMD -- __launch_bounds__(128, 2) on the NT = 1 form: 256 registers, 220-340 bytes of scratch on the chain -- was
 // measured: merit 554 -> 414 it/s, SS 450 -> 308)
-template <int M, bool FACT, int NT>
+template <int M, bool FACT, int NT, int PK = 0>   // PK: 1 = Pendulum3dDyanmics (dyn_f)
 __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0, int nslots, int direct, int list) {
   constexpr int NQ = 16 * NT;  // quads per workgroup
   const DConsts& C = *(const DConsts*)P.c;
@@ -2934,8 +2934,8 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
 #pragma unroll
       for (int a = 0; a < M; a++) un[a] = R.u[a] + du[a];
       State Fn;
-      if (DK.diag) dyn_twist_k<M, DConsts, 0>(DK, C, Sn, un, Fn);
-      else Fn = dyn_f<M, DConsts, 0>(C, Sn, un);
+      if (DK.diag) dyn_twist_k<M, DConsts, PK>(DK, C, Sn, un, Fn);
+      else Fn = dyn_f<M, DConsts, PK>(C, Sn, un);
       if constexpr (FACT) {  // xi^_{i+1} = (alpha - 1) d_xi + f_xi(x^_i, u^_i)   (roll_step)
         Sn.w = am1 * v3(d[0], d[1], d[2]) + Fn.w;
         Sn.v = am1 * v3(d[3], d[4], d[5]) + Fn.v;
@@ -4067,9 +4067,9 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
   // factors of :2713-2716 are the identity: note at the record layout) -- K3 itself, written straight into the candidate
   // arrays (every active trajectory is undecided at this point)
   const bool k3 = direct && a0 == 0 && !linear;
-  // the rollouts of a stage in two wavefronts per sixteen quads (k_rollout_ls2): the nonlinear rollouts of every model but the
-  // pendulum; TOLG_LS_ONEWAVE=1 keeps the one-wave forms (K3 for the first try, k_rollout_ls) for comparisons
-  const bool two = !linear && !pend && !getenv_flag("TOLG_LS_ONEWAVE");
+  // the rollouts of a stage in two wavefronts per sixteen quads (k_rollout_ls2): the nonlinear rollouts of every model (PK = 1: the
+  // pendulum); TOLG_LS_ONEWAVE=1 keeps the one-wave forms (K3 for the first try, k_rollout_ls) for comparisons
+  const bool two = !linear && !getenv_flag("TOLG_LS_ONEWAVE");
   if (k3 && !two) {
     int rc = run_rollout_ms<M>(h, P, st, 1.0, 0, MS ? 1 : 0);
     if (rc) return rc;
@@ -4089,7 +4089,11 @@ static int run_ls_stage(tolg_handle_s* h, const Params& P, hipStream_t st, int s
         // twist waves per workgroup (k_rollout_ls2): the merit search's stages are a few hundred quads -- one chain's length, and
         // a pose wave of its own per sixteen quads keeps that chain shortest (NT = 1; with NT = 3 merit 596 -> 526 it/s); single
         // shooting's twelve step sizes fill the chip several times over and gain from fewer waves per quad (NT = 3: SS 517 -> 542)
-        if (MS) {
+        if (pend) {  // (m = 6 only; one twist wave per pose wave in every stage)
+          const dim3 g2((P.Bp + 15) / 16, n), b2(128);
+          if (MS && !k3) hipLaunchKernelGGL((k_rollout_ls2<6, true, 1, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
+          else hipLaunchKernelGGL((k_rollout_ls2<6, false, 1, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
+        } else if (MS) {
           const dim3 g2((P.Bp + 15) / 16, n), b2(128);
           if (!k3) hipLaunchKernelGGL((k_rollout_ls2<M, true, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
           else hipLaunchKernelGGL((k_rollout_ls2<M, false, 1>), g2, b2, 0, st, P, a0, n, direct, list_in);
