@@ -861,8 +861,13 @@ TOLG_DEV void lin_knot(const Params& P, const CT& C, int i, int b, int ms, const
 }
 
 TOLG_DEV bool ls_quad_form(const Params& P, int list, int nslots);  // (line-search stages, below)
+// two waves per SIMD: the kernel needed 260 registers, four past the limit for a second wave -- at 256 (12 bytes of scratch for
+// m = 6) 0.232 -> 0.217 ms per call at 4096 x 200; three waves (168 registers, 284 bytes of scratch): 0.31 ms
+#ifndef TOLG_K1_WPE
+#define TOLG_K1_WPE 2
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_linearize(Params P, const double* __restrict__ src,
+__global__ __launch_bounds__(256, TOLG_K1_WPE) void k_linearize(Params P, const double* __restrict__ src,
                                                     const double* __restrict__ src_u, double* __restrict__ dst,
                                                     double* __restrict__ dst_u, int ms, int i0, int ni, int ls_list, int ls_nslots) {
   // knots [i0, i0 + ni); dst / dst_u (optional): the trajectory is copied there while it is read.
@@ -3050,6 +3055,7 @@ __global__ __launch_bounds__(64 * (NT + 1)) void k_rollout_ls2(Params P, int a0,
 }
 // stage cost l(x^_i, u^_i) (traopt_cost.py:675-738) and, MS, the squared defect
 // |Log(x^_{i+1}^-1 f_q(x^_i, u^_i))|^2 + |f_xi - xi^_{i+1}|^2 (:2790-2812) of every stored candidate of the stage
+// (four waves per SIMD -- 127 registers and 28 bytes of scratch instead of 136 -- was measured: no change)
 template <int M, bool MS>
 __global__ __launch_bounds__(256) void k_ls_eval(Params P, int nslots, int direct, int list) {
   const Consts& C = *P.c;
