@@ -34,9 +34,16 @@ def _fit(prob, x0_q, x0_xi, us0, K, mode, line_search, schedule):
     ("se3", "ms", False, 37, 45), ("se3", "ms", True, 21, 60), ("se3", "ss", False, 19, 33), ("drone", "ms", False, 9, 70),
     ("drone", "ms", True, 13, 41), ("drone", "ss", False, 6, 25), ("se3", "ms", False, 5, 1), ("se3", "ss", False, 4, 2),
     ("se3", "ms", True, 260, 40),   # more undecided trajectories than one workgroup of the evaluation holds
+    ("se3_dense", "ms", False, 17, 45), ("se3_dense", "ms", True, 11, 50), ("se3_dense", "ss", False, 9, 33),  # I + H dt from the record
 ])
 def test_affine_equals_statement_form_and_oracle(kind, mode, line_search, B, N):
     prob, x0_q, x0_xi, us0 = (workloads.drone_tracking if kind == "drone" else workloads.se3_tracking)(B, N=N, R_scale=1e-3)
+    if kind.endswith("_dense"):  # full inertia blocks (a rotated body frame's inertia): the sweep reads the velocity block from the record
+        A = np.array([[0.10, -0.05, 0.02], [0.03, 0.12, -0.04], [-0.02, 0.06, 0.09]])
+        Jd = np.array(prob.J, dtype=float).copy()
+        Jd[:3, :3] += A @ A.T
+        Jd[3:, 3:] += 0.5 * (A @ A.T)
+        prob = TrackingProblem("se3", Jd, prob.dt, prob.Q, prob.R, prob.P, prob.q_ref, prob.xi_ref)
     K = 5
     ra = _fit(prob, x0_q, x0_xi, us0, K, mode, line_search, "auto")
     rs = _fit(prob, x0_q, x0_xi, us0, K, mode, line_search, "split")

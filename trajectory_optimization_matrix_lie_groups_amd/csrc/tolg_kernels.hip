@@ -4049,8 +4049,14 @@ static void launch_ec_ring(const tolg_handle_s* h, const Params& P, hipStream_t 
 template <int M>
 static int run_affine_dev(tolg_handle_s* h, const Params& P, hipStream_t st, bool merit) {
   Timed t(h, st, 1);
-  if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true, true>), dim3(P.Bp / 4), dim3(64), 0, st, P);
-  else hipLaunchKernelGGL((k_expected_change_ring<M, false, true>), dim3(P.Bp / 4), dim3(64), 0, st, P);
+  const dim3 gr(P.Bp / 4), blk(64);
+  if (P.fA22 >= 0) {  // dense inertia blocks: the velocity block from the record run
+    if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true, true, true>), gr, blk, 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change_ring<M, false, true, true>), gr, blk, 0, st, P);
+  } else {
+    if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true, true>), gr, blk, 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change_ring<M, false, true>), gr, blk, 0, st, P);
+  }
   LAUNCH_CHECK();
   if (merit) {
     hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
@@ -4297,7 +4303,7 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
   P.max_reg = opt->max_reg;
   // rollout = 'linear' as an affine recursion (k_expected_change_ring<.., STORE>): the models of the third backward form;
   // TOLG_SCHED_SPLIT keeps the statement-form rollouts for every trajectory (the A/B partner in the tests)
-  P.affine = (opt->rollout_linear && P.fA22 < 0 && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT) ? 1 : 0;
+  P.affine = (opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT) ? 1 : 0;
   size_t n = (size_t)(P.N + 1) * P.Bp;
   hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, ms);
   LAUNCH_CHECK();
