@@ -216,7 +216,8 @@ def test_gpu_pendulum_merit_search_ring_and_statement_schedules_agree():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,line_search,rollout", [("ms", True, "nonlinear"), ("ms", False, "nonlinear"),
-                                                      ("ss", False, "nonlinear"), ("ms", False, "linear")])
+                                                      ("ss", False, "nonlinear"), ("ms", False, "linear"),
+                                                      ("ms", True, "linear"), ("ss", False, "linear")])  # (the affine path: every candidate from one sweep)
 def test_gpu_pendulum_fit_matches_oracle(mode, line_search, rollout):
     from trajectory_optimization_matrix_lie_groups_amd import BatchedTrackingILQR
     B, K = 6, 12

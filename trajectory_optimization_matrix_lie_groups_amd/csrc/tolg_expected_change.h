@@ -77,7 +77,6 @@ TOLG_DEV void ec_dma4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, 
 // record's REC_BU (which takes REC_TRI's place; the block it displaces is zero for this model) and is read from the ring.
 template <int M, bool GRAV, bool STORE = false, bool DENSE = false, bool VARB = false>
 __global__ __launch_bounds__(64) void k_expected_change_ring(Params P) {
-  static_assert(!(STORE && VARB), "the affine linear-rollout path serves the models with a constant input matrix");
   static_assert(!VARB || (DENSE && GRAV && M == 6), "VARB: the pendulum's instantiation");
   typedef EcLds<DENSE> L;
   constexpr unsigned EC_RECB = L::RECB, EC_ZP = L::ZP, EC_SLOT = L::SLOT, EC_SCR = L::SCR, EC_LDS = L::LDS;

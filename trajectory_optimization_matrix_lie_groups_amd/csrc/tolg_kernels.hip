@@ -4050,7 +4050,10 @@ template <int M>
 static int run_affine_dev(tolg_handle_s* h, const Params& P, hipStream_t st, bool merit) {
   Timed t(h, st, 1);
   const dim3 gr(P.Bp / 4), blk(64);
-  if (P.fA22 >= 0) {  // dense inertia blocks: the velocity block from the record run
+  const bool pend = M == 6 && h->prob.kind == TOLG_DYN_PENDULUM3D;
+  if (pend) {  // (the knot's input-matrix block from the record run as well)
+    hipLaunchKernelGGL((k_expected_change_ring<6, true, true, true, true>), gr, blk, 0, st, P);
+  } else if (P.fA22 >= 0) {  // dense inertia blocks: the velocity block from the record run
     if (h->hc.grav != 0.0) hipLaunchKernelGGL((k_expected_change_ring<M, true, true, true>), gr, blk, 0, st, P);
     else hipLaunchKernelGGL((k_expected_change_ring<M, false, true, true>), gr, blk, 0, st, P);
   } else {
@@ -4059,7 +4062,8 @@ static int run_affine_dev(tolg_handle_s* h, const Params& P, hipStream_t st, boo
   }
   LAUNCH_CHECK();
   if (merit) {
-    hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+    if (pend) hipLaunchKernelGGL((k_expected_change<6, 1, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((k_expected_change<M, 0, true>), dim3((P.Bp * 4 + 63) / 64), dim3(64), 0, st, P);
     LAUNCH_CHECK();
   }
   return 0;
@@ -4301,9 +4305,9 @@ extern "C" int tolg_solve_begin(tolg_handle_t h, const tolg_options* opt, int32_
   P.J_hist = d_J_hist; P.grad_hist = d_grad_hist; P.defect_hist = d_defect_hist; P.alpha_hist = d_alpha_hist;
   P.mu_hist = d_mu_hist; P.max_iter = opt->max_iter; P.tol_grad = opt->tol_grad; P.tol_defect = opt->tol_defect;
   P.max_reg = opt->max_reg;
-  // rollout = 'linear' as an affine recursion (k_expected_change_ring<.., STORE>): the models of the third backward form;
+  // rollout = 'linear' as an affine recursion (k_expected_change_ring<.., STORE>): every model since the end of round 4;
   // TOLG_SCHED_SPLIT keeps the statement-form rollouts for every trajectory (the A/B partner in the tests)
-  P.affine = (opt->rollout_linear && h->prob.kind != TOLG_DYN_PENDULUM3D && opt->schedule != TOLG_SCHED_SPLIT) ? 1 : 0;
+  P.affine = (opt->rollout_linear && opt->schedule != TOLG_SCHED_SPLIT) ? 1 : 0;
   size_t n = (size_t)(P.N + 1) * P.Bp;
   hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_x0_q, d_x0_xi, d_us_init, ms);
   LAUNCH_CHECK();
