@@ -5,6 +5,9 @@ tag=${1:-rXX}; out=gpurun_out
 for spec in "headline:" "ss:--mode ss" "merit:--line-search" "linear_ms:--rollout linear" "linear_merit:--rollout linear --line-search" \
             "linear_ss:--rollout linear --mode ss" "dense:--inertia dense" "dense_ss:--inertia dense --mode ss" "dense_merit:--inertia dense --line-search" \
             "pendulum:--workload pendulum" "pendulum_ss:--workload pendulum --mode ss" "pendulum_merit:--workload pendulum --line-search" \
+            "dense_linear_ms:--inertia dense --rollout linear" "dense_linear_ss:--inertia dense --rollout linear --mode ss" \
+            "dense_linear_merit:--inertia dense --rollout linear --line-search" \
+            "pendulum_linear_ss:--workload pendulum --rollout linear --mode ss" "pendulum_linear_merit:--workload pendulum --rollout linear --line-search" \
             "se3_8192:--batch 8192" "drone400_8192:--workload drone400" "se3_256:--batch 256" "al1024:--workload al1024" "so3:--workload so3"; do
   name=${spec%%:*}; flags=${spec#*:}
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --repeats 6 --fresh-regions 0 $flags > $out/${tag}_bench_${name}.json 2> $out/${tag}_bench_${name}.err
