@@ -95,6 +95,47 @@ def draw(seed, nkinds=None):
     return dict(kind=kind, diag=diag, mode=mode, line_search=line_search, rollout=rollout, B=B, N=N, K=K), prob, x0_q, x0_xi, us0
 
 
+_PD_CACHE = {}
+
+
+def pd_flip(b, solver, op, cfg, x0_q, x0_xi, us0, st, o, mu_g, mu_o, Jg):
+    """One side of trajectory b ran clean, the other regularised to the limit / went non-finite.  Give the clean side the failing
+    side's trajectory at the sweep where the two part (k = first iteration whose regularisation differs) and run ITS backward pass
+    on it: True if it then regularises past max_reg as well -- the decision belongs to the trajectory's last digits, not to the
+    implementation."""
+    n = min(len(mu_g), len(mu_o))
+    ks = [k for k in range(n) if (mu_g[k] > 0) != (mu_o[k] > 0) or not np.isfinite(Jg[b, k]) or not np.isfinite(o["J_hist"][b, k])]
+    if not ks:
+        return False
+    k, ms = ks[0], cfg["mode"] == "ms"
+    kw = dict(mode=cfg["mode"], line_search=cfg["line_search"], rollout=cfg["rollout"])
+    try:
+        if o["status"][b] == 0:   # the GPU failed: the oracle's sweep on the GPU's trajectory
+            key = ("g", id(solver), k)
+            if key not in _PD_CACHE:
+                _PD_CACHE.clear()
+                if k == 0:
+                    _PD_CACHE[key] = None
+                else:
+                    rk = solver.fit_batch(x0_q, x0_xi, us0, n_iterations=k, tol_grad_norm=0.0, tol_d_norm=0.0, **kw)
+                    _PD_CACHE[key] = (rk.xs_q.cpu().numpy(), rk.xs_xi.cpu().numpy(), rk.us.cpu().numpy())
+            if _PD_CACHE[key] is None:
+                return False
+            xq, xx, uu = _PD_CACHE[key]
+            lb = ob.lin_backward(op, xq[b], xx[b], uu[b], ms=ms, mu=0.0)
+            return bool(lb["mu"] >= 1e10 or not np.isfinite(lb["grad"]))
+        # the oracle failed: the GPU's sweep on the oracle's trajectory
+        if k == 0:
+            return False
+        ok_ = ob.fit_batch(op, x0_q, x0_xi, us0, max_iter=k, **kw)
+        g = solver.linearize_backward(ok_["xs_q"], ok_["xs_xi"], ok_["us"], ms=ms)
+        md = g["mu_delta"].cpu().numpy()
+        return bool(md[b, 0] >= 1e10 or not np.isfinite(float(g["grad"][b])))
+    except Exception as e:   # (the check is a courtesy: a failure of it leaves the case flagged)
+        print("pd_flip: %s" % e, flush=True)
+        return False
+
+
 def one(seed, nkinds=None):
     cfg, prob, x0_q, x0_xi, us0 = draw(seed, nkinds)
     K, B = cfg["K"], cfg["B"]
@@ -169,7 +210,13 @@ def one(seed, nkinds=None):
             if it[b] != o["iters"][b] or st[b] != o["status"][b]:
                 stats["ill_exit_differs"] = stats.get("ill_exit_differs", 0) + 1
                 if (st[b] == 0) != (o["status"][b] == 0):
-                    notes.append("b%d (ill-conditioned) status %d/%d: one side clean, the other failed" % (b, st[b], o["status"][b]))
+                    # ... unless the side that stayed clean takes the OTHER side's decision when it is given the other side's
+                    # trajectory: the positive-definiteness test of one sweep hangs on the last digits of a trajectory the two
+                    # agree on to 1e-15 (seeds 50312, 50349: profiles/r04c_parity_fuzz_final_tree.txt).  Counted, not hidden.
+                    if pd_flip(b, solver, op, cfg, x0_q, x0_xi, us0, st, o, mu_g, mu_o, Jg):
+                        stats["ill_pd_flip"] = stats.get("ill_pd_flip", 0) + 1
+                    else:
+                        notes.append("b%d (ill-conditioned) status %d/%d: one side clean, the other failed" % (b, st[b], o["status"][b]))
             if n_cmp:
                 with np.errstate(all="ignore"):
                     e = np.abs(Jg[b, :n_cmp] - jo[:n_cmp]) / np.abs(jo[:n_cmp]) / np.maximum(TOL_J, 10.0 * nf[:n_cmp])
