@@ -595,11 +595,14 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
 #define TOLG_K3_SYMP 4
 #endif
     static_assert(TOLG_K3_SYMP >= 1 && (TOLG_K3_SYMP & (TOLG_K3_SYMP - 1)) == 0, "symmetrisation period: a power of two");
-#if TOLG_K3_SYMP <= 2
-    constexpr bool sym_now = TOLG_K3_SYMP == 1 || SLOT == 0;
-#else
-    const bool sym_now = SLOT == 0 && (i & (TOLG_K3_SYMP - 1)) == 0;
-#endif
+    // The FULL kernel symmetrises at every knot, as the reference does (round 4, end).  The growth bound above was measured on
+    // solves that converge; far into a divergence -- |F_x| of 1e3 .. 7e4, |V| of 1e17, an input weight of 1e-6 -- the mode
+    // outgrows four knots: V_SS came out indefinite at a knot where the oracle's was positive definite, in two of 700 random
+    // problems (seeds 50312 and 50349, profiles/r04c_parity_fuzz_final_tree.txt; period 2 cured one, period 1 both).  The fast
+    // kernel keeps the period: such a sweep meets a non-positive pivot, hands its group back, and the full kernel redoes it from
+    // the terminal knot with the antisymmetric part removed at every knot.
+    constexpr int SYMP = FAST ? TOLG_K3_SYMP : 1;
+    const bool sym_now = SYMP == 1 || (SLOT == 0 && (SYMP == 2 || (i & (SYMP - 1)) == 0));
     if (sym_now) {
 #pragma unroll
       for (int r = 0; r < 12; r++) *reinterpret_cast<double*>(lds + wTR + r * (B3_TRS * 8)) = Qh[r];
@@ -772,7 +775,8 @@ __global__ __launch_bounds__(64) void k_backward3(Params P, int it, int flags) {
     // fast attempt that dies half way every other sweep.  Regularisation that is merely left over on entry and decays -- the
     // first sweep of every solve starts from mu = 1 -- does not count: the fast kernel checks mu itself.)
     const bool anyf = __any(failed);
-    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = anyf ? 8 : (hn > 0 ? hn - 1 : 0); }
+    // (the first sweep of a solve starts the count: what the workspace held before is not a hint)
+    if (lane == 0) { const int hn = (it == 0) ? 0 : P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = anyf ? 8 : (hn > 0 ? hn - 1 : 0); }
   }
   store_gains(P.GK);
 #ifdef TOLG_STAMPS

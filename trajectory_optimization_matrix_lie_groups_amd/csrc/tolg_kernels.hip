@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(64) void k_backward(Params P, int it, int flags) {
     }
   } else {
     // (the hint counts down from eight after a sweep with a non-positive pivot: note in tolg_backward3.h)
-    if (lane == 0) { const int hn = P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
+    if (lane == 0) { const int hn = (it == 0) ? 0 : P.k2_hint[blockIdx.x]; P.k2_hint[blockIdx.x] = failed ? 8 : (hn > 0 ? hn - 1 : 0); }
   }
   store_gains(0);
 #ifdef TOLG_STAMPS
