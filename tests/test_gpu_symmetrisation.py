@@ -1,5 +1,7 @@
-"""The backward sweep symmetrises Q_xx every fourth knot (TOLG_K3_SYMP = 4, csrc/tolg_backward3.h); the reference symmetrises
-V at every knot (traopt_controller.py:3004).  The antisymmetric part of V is an unstable mode of the sweep's form of the
+"""The FAST backward sweep symmetrises Q_xx every fourth knot (TOLG_K3_SYMP = 4, csrc/tolg_backward3.h); the reference symmetrises
+V at every knot (traopt_controller.py:3004), and so does the full kernel since the end of round 4 (the first sweep of a solve, a single
+sweep through linearize_backward, every group the fast sweep hands back: tests/test_gpu_fuzz.py::test_seeds_the_campaigns_flagged is
+where the period was outgrown).  tests/test_gpu_k2_fast.py compares the two kernels -- i.e. the two periods -- directly.  The antisymmetric part of V is an unstable mode of the sweep's form of the
 recursion, so the period is a numerical choice that needs a bound where it is most exposed: long horizons and small input
 weights (the per-knot growth factor is largest there).  Checked against the oracle, which symmetrises every knot: gains,
 value-function gradient term and the iterates of a few iterations at N = 400 (drone, R = 1e-5 .. 1e-3) and N = 955 (SE3)."""
@@ -32,9 +34,9 @@ def test_sweep_with_four_knot_symmetrisation_matches_every_knot_oracle(kind, N, 
         per_knot = np.abs(Kg - Ko).max(axis=(1, 2)) / np.abs(Ko).max(axis=(1, 2))
         assert per_knot.max() < 1e-9, (b, int(per_knot.argmax()), per_knot.max())   # no growth along the horizon
         assert float(r["grad"][b]) == pytest.approx(o["grad"], rel=1e-9)
-    # and two accept-always iterations end to end
-    rr = BatchedTrackingILQR(prob, B).fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=2, tol_grad_norm=0.0, tol_d_norm=0.0)
-    oo = ob.fit_batch(op, x0_q, x0_xi, us0, mode="ms", max_iter=2)
+    # and four accept-always iterations end to end (the sweeps of the second to fourth are the fast kernel's: every fourth knot)
+    rr = BatchedTrackingILQR(prob, B).fit_batch(x0_q, x0_xi, us0, mode="ms", n_iterations=4, tol_grad_norm=0.0, tol_d_norm=0.0)
+    oo = ob.fit_batch(op, x0_q, x0_xi, us0, mode="ms", max_iter=4)
     ok = np.isfinite(oo["J_hist"]).all(axis=1) & (np.abs(oo["J_hist"]).max(axis=1) < 1e12)
     assert ok.sum() >= 1
     assert _rel(rr.J_hist.cpu().numpy()[ok], oo["J_hist"][ok]) < 1e-9

@@ -31,7 +31,9 @@
 //    every knot either (the reference symmetrises every knot, :3004): since late round 3 every TOLG_K3_SYMP-th knot
 //    (4; note at `sym_now` below) -- between two symmetrisations the mode grows by ~1.1 per knot on the benchmark
 //    workload (4 at worst), i.e. to < 3e-14 of |V| before it is removed; tests/test_gpu_symmetrisation.py bounds the
-//    difference to a build that symmetrises every knot on a long-horizon, low-R drone problem.
+//    difference to the every-knot oracle on long-horizon, low-R problems.  Since the end of round 4 that period is the FAST
+//    kernel's alone: the full kernel symmetrises at every knot (note at `sym_now`: far into a divergence the mode outgrows
+//    four knots, and a fast sweep that meets a non-positive pivot hands its group to the full kernel).
 template <int M>
 __host__ __device__ constexpr int urow(int u) { return (u < 3 || M == 6) ? 6 + u : 11; }  // state row driven by input u
 
