@@ -922,6 +922,10 @@ __global__ void k_reduce(Params P, int it) {
   for (; i < P.N; i++) { J += P.SC[(size_t)i * P.Bp + b]; d2 += P.SD[(size_t)i * P.Bp + b]; }
   J += P.SC[(size_t)P.N * P.Bp + b];
   double dn = sqrt(d2);
+  // a cost that grows tenfold in an iteration: the solve is diverging (accept-always steps only: the searches take no such step).
+  // The fast backward sweep's four-knot symmetrisation period was measured on solves that converge (tolg_backward3.h); a group
+  // with such a member takes the full kernel -- every knot, like the reference -- for its next sweeps.
+  if (it >= 0 && b < P.B && J > 10.0 * P.Jc[b]) P.k2_hint[b >> 2] = 8;
   P.Jc[b] = J;
   P.dn[b] = dn;
   if (b >= P.B) return;
@@ -2540,6 +2544,7 @@ __global__ __launch_bounds__(256) void k_rollout_lin(Params P, int it) {
     for (int hh = 0; hh < RL_NH; hh++)
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) J += lpart[hh][k4][tt];
+    if (b < P.B && J > 10.0 * P.Jc[b]) P.k2_hint[b >> 2] = 8;  // a diverging solve: its group's next sweeps are the full kernel's (k_reduce)
     P.Jc[b] = J;
     P.dn[b] = 0.0;  // closed by construction
     if (b < P.B) {
